@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FIX = os.path.join(HERE, "golden", "fixtures")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def fixture_bytes(name):
+    with open(os.path.join(FIX, name), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def dict_naive():
+    return fixture_bytes("dict_naive")
+
+
+@pytest.fixture(scope="session")
+def average_block():
+    return fixture_bytes("average_block.bin")
