@@ -1,0 +1,606 @@
+// capi.hip - host side of libmi355_lzss.so: the C ABI of include/mi355_lzss.h over the HIP kernels.
+// There is no CPU fallback in here: every data-path entry point launches kernels or fails.
+#include "../../include/mi355_lzss.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace lzss;
+
+// ---- errors ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(MI355_LZSS_E_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *mi355_lzss_last_error(void) { return g_err; }
+
+// ---- device memory helpers ------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {  // grows (never shrinks); contents are NOT preserved
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T *as() const { return (T *)p; }
+};
+
+struct PinBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        HIP_TRY(hipHostMalloc(&p, need, hipHostMallocDefault));
+        bytes = need;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T *as() const { return (T *)p; }
+};
+
+static inline uint64_t seg_stride(uint64_t n) { return (n + SEG_PAD + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN; }
+
+// ---- objects ----------------------------------------------------------------------------------------
+enum { ST_SA = 0, ST_LCP, ST_MATCH, ST_DECIDE, ST_WALK, ST_EMIT, ST_DECOMP, ST_COUNT };
+static const char *const kStageNames[ST_COUNT] = {"sa_build", "lcp", "match", "decide", "walk", "emit", "decompress"};
+
+struct mi355_lzss_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<uint8_t> dict;  // augmented
+    int32_t res_idx[2] = {0, 0};
+    // dictionary index on the device
+    DevBuf d_text, d_sa, d_isa, d_lcp, d_b1, d_b2;
+    DictView view{};
+    mi355_lzss_batch *scratch = nullptr;  // for the single-buffer entry points
+};
+
+struct mi355_lzss_batch {
+    mi355_lzss_ctx *ctx = nullptr;
+    uint32_t max_blobs = 0;
+    uint64_t cap_elems = 0;  // element capacity of the per-position arrays
+    // per-position arrays
+    DevBuf text, keyA, valA, keyB, valB, rkA, rkB, flags, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
+    DevBuf entry, tilebit, headb, tailb;  // per 256-tile
+    DevBuf segs, nbits, out_off, out_len, status;  // per blob
+    DevBuf out;                                    // compressed bytes, blob b at out_off[b]
+    PinBuf h_stage;                                // pinned staging for uploads / downloads
+    std::vector<Seg> h_segs;
+    std::vector<uint64_t> h_out_off;
+    std::vector<uint32_t> h_out_len;
+    std::vector<uint64_t> h_nbits;
+    std::vector<int32_t> h_status, h_pre_status;
+    uint32_t n_blobs = 0, max_n = 0;
+    uint64_t used_elems = 0;
+    bool have_sizes = false;
+    uint32_t header_bytes = 0;
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    bool ev_valid[ST_COUNT + 1] = {};
+    float stage_ms[ST_COUNT] = {};
+    // decompression side
+    DevBuf d_cin, d_cin_off, d_dout, d_dout_off, d_dlen, d_dstatus;
+    std::vector<uint64_t> h_cin_off, h_dout_off;
+    uint32_t n_dblobs = 0;
+};
+
+static int set_device(const mi355_lzss_ctx *ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return 0;
+}
+
+// ---- batch workspace --------------------------------------------------------------------------------
+static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems) {
+    int rc;
+    if (elems > b->cap_elems) {
+        const uint64_t e = elems;
+#define R(buf, bytes_per) if ((rc = b->buf.ensure((size_t)(e * (bytes_per)))) != 0) return rc;
+        R(text, 1) R(keyA, 4) R(valA, 4) R(keyB, 4) R(valB, 4) R(rkA, 4) R(rkB, 4) R(flags, 1)
+        R(sa, 4) R(isa, 4) R(lcp, 2) R(res, 4) R(adv, 1) R(kind, 1) R(exitoff, 1)
+#undef R
+        const uint64_t e64 = e / 64 + 1, e256 = e / 256 + 1;
+        if ((rc = b->b1.ensure(e64 * 2)) != 0) return rc;
+        if ((rc = b->b2.ensure(e64 * 2)) != 0) return rc;
+        if ((rc = b->entry.ensure(e256 * 2)) != 0) return rc;
+        if ((rc = b->tilebit.ensure(e256 * 8)) != 0) return rc;
+        if ((rc = b->headb.ensure(e256)) != 0) return rc;
+        if ((rc = b->tailb.ensure(e256)) != 0) return rc;
+        b->cap_elems = elems;
+    }
+    if (max_blobs > b->max_blobs) {
+        const size_t m = max_blobs;
+        if ((rc = b->segs.ensure(m * sizeof(Seg))) != 0) return rc;
+        if ((rc = b->nbits.ensure(m * 8)) != 0) return rc;
+        if ((rc = b->out_off.ensure((m + 1) * 8)) != 0) return rc;
+        if ((rc = b->out_len.ensure(m * 4)) != 0) return rc;
+        if ((rc = b->status.ensure(m * 4)) != 0) return rc;
+        b->max_blobs = max_blobs;
+    }
+    return 0;
+}
+
+static SaWork sa_work(mi355_lzss_batch *b) {
+    SaWork w;
+    w.keyA = b->keyA.as<int32_t>(); w.valA = b->valA.as<int32_t>();
+    w.keyB = b->keyB.as<int32_t>(); w.valB = b->valB.as<int32_t>();
+    w.rkA = b->rkA.as<int32_t>(); w.rkB = b->rkB.as<int32_t>();
+    w.flags = b->flags.as<uint8_t>();
+    w.sa = b->sa.as<int32_t>(); w.isa = b->isa.as<int32_t>();
+    return w;
+}
+static BatchIndex batch_index(mi355_lzss_batch *b) {
+    BatchIndex ix;
+    ix.text = b->text.as<uint8_t>();
+    ix.sa = b->sa.as<int32_t>(); ix.isa = b->isa.as<int32_t>();
+    ix.lcp = b->lcp.as<uint16_t>(); ix.bmin1 = b->b1.as<uint16_t>(); ix.bmin2 = b->b2.as<uint16_t>();
+    return ix;
+}
+static WalkWork walk_work(mi355_lzss_batch *b) {
+    WalkWork w;
+    w.adv = b->adv.as<uint8_t>(); w.kind = b->kind.as<uint8_t>(); w.exitoff = b->exitoff.as<uint8_t>();
+    w.entry = b->entry.as<uint16_t>(); w.tilebit = b->tilebit.as<uint64_t>();
+    w.headb = b->headb.as<uint8_t>(); w.tailb = b->tailb.as<uint8_t>();
+    w.nbits = b->nbits.as<uint64_t>(); w.out_off = b->out_off.as<uint64_t>(); w.out_len = b->out_len.as<uint32_t>();
+    return w;
+}
+
+static int mark(mi355_lzss_batch *b, int k) {
+    if (!b->ev_valid[k]) {
+        HIP_TRY(hipEventCreate(&b->ev[k]));
+        b->ev_valid[k] = true;
+    }
+    HIP_TRY(hipEventRecord(b->ev[k], b->ctx->stream));
+    return 0;
+}
+
+extern "C" int mi355_lzss_batch_create(mi355_lzss_ctx *ctx, uint32_t max_blobs, uint64_t max_total_bytes,
+                                       mi355_lzss_batch **out) {
+    if (!ctx || !out) return fail(MI355_LZSS_E_ARG, "null argument");
+    int rc;
+    if ((rc = set_device(ctx)) != 0) return rc;
+    mi355_lzss_batch *b = new mi355_lzss_batch();
+    b->ctx = ctx;
+    if (max_blobs == 0) max_blobs = 1;
+    const uint64_t elems = max_total_bytes + (uint64_t)max_blobs * (SEG_PAD + SEG_ALIGN);
+    if ((rc = batch_reserve(b, max_blobs, elems)) != 0) {
+        mi355_lzss_batch_destroy(b);
+        return rc;
+    }
+    *out = b;
+    return 0;
+}
+
+extern "C" void mi355_lzss_batch_destroy(mi355_lzss_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    DevBuf *bufs[] = {&b->text, &b->keyA, &b->valA, &b->keyB, &b->valB, &b->rkA, &b->rkB, &b->flags, &b->sa, &b->isa,
+                      &b->lcp, &b->b1, &b->b2, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
+                      &b->headb, &b->tailb, &b->segs, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->out,
+                      &b->d_cin, &b->d_cin_off, &b->d_dout, &b->d_dout_off, &b->d_dlen, &b->d_dstatus};
+    for (DevBuf *d : bufs) d->release();
+    b->h_stage.release();
+    for (int k = 0; k <= ST_COUNT; ++k)
+        if (b->ev_valid[k]) (void)hipEventDestroy(b->ev[k]);
+    delete b;
+}
+
+extern "C" int mi355_lzss_batch_upload(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
+                                       const uint32_t *starts) {
+    if (!b || !in_off || (n_blobs && !in)) return fail(MI355_LZSS_E_ARG, "null argument");
+    int rc;
+    if ((rc = set_device(b->ctx)) != 0) return rc;
+    uint64_t elems = 0;
+    uint32_t max_n = 0;
+    b->h_segs.assign(n_blobs, Seg{});
+    b->h_pre_status.assign(n_blobs, 0);
+    for (uint32_t k = 0; k < n_blobs; ++k) {
+        if (in_off[k + 1] < in_off[k]) return fail(MI355_LZSS_E_ARG, "in_off must be non-decreasing");
+        uint64_t n = in_off[k + 1] - in_off[k];
+        if (n > LZSS_MAX_INPUT_SIZE) {  // compress.go:473-475
+            b->h_pre_status[k] = MI355_LZSS_E_INPUT_SIZE;
+            n = 0;
+        }
+        uint32_t st = starts ? starts[k] : 0;
+        if (st > n) st = (uint32_t)n;
+        b->h_segs[k] = Seg{elems, (uint32_t)n, st};
+        elems += seg_stride(n);
+        max_n = std::max<uint32_t>(max_n, (uint32_t)n);
+    }
+    if ((rc = batch_reserve(b, std::max<uint32_t>(n_blobs, 1), std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
+    if ((rc = b->h_stage.ensure((size_t)std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
+    uint8_t *st = b->h_stage.as<uint8_t>();
+    for (uint32_t k = 0; k < n_blobs; ++k) {
+        const Seg &s = b->h_segs[k];
+        if (s.n) memcpy(st + s.off, in + in_off[k], s.n);
+        memset(st + s.off + s.n, 0, (size_t)(seg_stride(s.n) - s.n));
+    }
+    hipStream_t sm = b->ctx->stream;
+    if (elems) HIP_TRY(hipMemcpyAsync(b->text.p, st, (size_t)elems, hipMemcpyHostToDevice, sm));
+    if (n_blobs) HIP_TRY(hipMemcpyAsync(b->segs.p, b->h_segs.data(), n_blobs * sizeof(Seg), hipMemcpyHostToDevice, sm));
+    HIP_TRY(hipStreamSynchronize(sm));
+    b->n_blobs = n_blobs;
+    b->max_n = max_n;
+    b->used_elems = elems;
+    b->have_sizes = false;
+    return 0;
+}
+
+// index build + match search for the uploaded blobs
+static int run_index_and_match(mi355_lzss_batch *b) {
+    hipStream_t sm = b->ctx->stream;
+    int rc;
+    const Seg *d_segs = b->segs.as<Seg>();
+    if ((rc = mark(b, ST_SA)) != 0) return rc;
+    launch_sa_build(d_segs, b->n_blobs, b->text.as<uint8_t>(), sa_work(b), sm);
+    if ((rc = mark(b, ST_LCP)) != 0) return rc;
+    launch_lcp(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
+    if ((rc = mark(b, ST_MATCH)) != 0) return rc;
+    launch_match(d_segs, b->n_blobs, b->max_n, batch_index(b), b->ctx->view, b->res.as<uint32_t>(), sm);
+    if ((rc = mark(b, ST_DECIDE)) != 0) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int collect_stage_times(mi355_lzss_batch *b, int first, int last) {
+    for (int k = 0; k < ST_COUNT; ++k) b->stage_ms[k] = 0.f;
+    for (int k = first; k < last; ++k) {
+        float ms = 0.f;
+        if (b->ev_valid[k] && b->ev_valid[k + 1]) HIP_TRY(hipEventElapsedTime(&ms, b->ev[k], b->ev[k + 1]));
+        b->stage_ms[k] = ms;
+    }
+    return 0;
+}
+
+// decide + walk (+ emit when emit != 0).  bit_off: first bit inside the first stream byte.
+static int run_walk_emit(mi355_lzss_batch *b, uint32_t header_bytes, uint32_t bit_off, bool emit) {
+    mi355_lzss_ctx *ctx = b->ctx;
+    hipStream_t sm = ctx->stream;
+    int rc;
+    const Seg *d_segs = b->segs.as<Seg>();
+    WalkWork ww = walk_work(b);
+    launch_decide(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), b->res.as<uint32_t>(), ww, sm);
+    if ((rc = mark(b, ST_WALK)) != 0) return rc;
+    launch_walk(d_segs, b->n_blobs, ww, header_bytes, bit_off, sm);
+    launch_out_offsets(b->n_blobs, ww, sm);
+    if ((rc = mark(b, ST_EMIT)) != 0) return rc;
+    b->h_out_off.assign(b->n_blobs + 1, 0);
+    b->h_out_len.assign(b->n_blobs, 0);
+    b->h_nbits.assign(b->n_blobs, 0);
+    b->h_status.assign(b->n_blobs, 0);
+    uint64_t total = 0;
+    if (emit) {
+        // the total size decides the capacity of the output buffer (8-byte read back, then emit)
+        HIP_TRY(hipMemcpyAsync(&total, ww.out_off + b->n_blobs, 8, hipMemcpyDeviceToHost, sm));
+        HIP_TRY(hipStreamSynchronize(sm));
+        if ((rc = b->out.ensure((size_t)std::max<uint64_t>(total, 16))) != 0) return rc;
+        launch_emit(d_segs, b->n_blobs, b->text.as<uint8_t>(), b->res.as<uint32_t>(), ww, header_bytes, bit_off,
+                    (uint32_t)ctx->dict.size(), ctx->res_idx[0], ctx->res_idx[1], b->out.as<uint8_t>(), b->out.bytes,
+                    b->status.as<int32_t>(), sm);
+    }
+    if ((rc = mark(b, ST_EMIT + 1)) != 0) return rc;
+    if (b->n_blobs) {
+        HIP_TRY(hipMemcpyAsync(b->h_out_off.data(), ww.out_off, (b->n_blobs + 1) * 8, hipMemcpyDeviceToHost, sm));
+        HIP_TRY(hipMemcpyAsync(b->h_out_len.data(), ww.out_len, b->n_blobs * 4, hipMemcpyDeviceToHost, sm));
+        HIP_TRY(hipMemcpyAsync(b->h_nbits.data(), ww.nbits, b->n_blobs * 8, hipMemcpyDeviceToHost, sm));
+        if (emit) HIP_TRY(hipMemcpyAsync(b->h_status.data(), b->status.p, b->n_blobs * 4, hipMemcpyDeviceToHost, sm));
+    }
+    HIP_TRY(hipStreamSynchronize(sm));
+    HIP_TRY(hipGetLastError());
+    b->have_sizes = true;
+    b->header_bytes = header_bytes;
+    return 0;
+}
+
+extern "C" int mi355_lzss_batch_compress(mi355_lzss_batch *b, int with_header) {
+    if (!b) return fail(MI355_LZSS_E_ARG, "null argument");
+    int rc;
+    if ((rc = set_device(b->ctx)) != 0) return rc;
+    if ((rc = run_index_and_match(b)) != 0) return rc;
+    if ((rc = run_walk_emit(b, with_header ? LZSS_HEADER_SIZE : 0, 0, true)) != 0) return rc;
+    return collect_stage_times(b, ST_SA, ST_EMIT + 1);
+}
+
+extern "C" int mi355_lzss_batch_sizes(mi355_lzss_batch *b, uint32_t *out_len, uint64_t *nbits, uint64_t *total) {
+    if (!b || !b->have_sizes) return fail(MI355_LZSS_E_ARG, "no compressed batch");
+    uint64_t t = 0;
+    for (uint32_t k = 0; k < b->n_blobs; ++k) {
+        if (out_len) out_len[k] = b->h_out_len[k];
+        if (nbits) nbits[k] = b->h_nbits[k];
+        t += b->h_out_len[k];
+    }
+    if (total) *total = t;
+    return 0;
+}
+
+extern "C" int mi355_lzss_batch_download(mi355_lzss_batch *b, uint8_t *out, const uint64_t *out_off, int32_t *status) {
+    if (!b || !b->have_sizes || !out_off || (b->n_blobs && !out)) return fail(MI355_LZSS_E_ARG, "bad argument");
+    int rc;
+    if ((rc = set_device(b->ctx)) != 0) return rc;
+    const uint64_t total = b->n_blobs ? b->h_out_off[b->n_blobs] : 0;
+    if (total == 0) return 0;
+    if ((rc = b->h_stage.ensure((size_t)total)) != 0) return rc;
+    hipStream_t sm = b->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(b->h_stage.p, b->out.p, (size_t)total, hipMemcpyDeviceToHost, sm));
+    HIP_TRY(hipStreamSynchronize(sm));
+    int worst = 0;
+    for (uint32_t k = 0; k < b->n_blobs; ++k) {
+        int32_t st = b->h_pre_status[k] ? b->h_pre_status[k] : b->h_status[k];
+        const uint64_t cap = out_off[k + 1] - out_off[k];
+        if (st == 0 && b->h_out_len[k] > cap) st = MI355_LZSS_E_CAPACITY;
+        if (st == 0) memcpy(out + out_off[k], b->h_stage.as<uint8_t>() + b->h_out_off[k], b->h_out_len[k]);
+        if (status) status[k] = st;
+        if (st && !worst) worst = st;
+    }
+    if (worst && !status) return fail(worst, "blob failed with status %d", worst);
+    return 0;
+}
+
+extern "C" int mi355_lzss_batch_results(mi355_lzss_batch *b, uint32_t blob, uint32_t *packed, size_t n) {
+    if (!b || blob >= b->n_blobs || !packed) return fail(MI355_LZSS_E_ARG, "bad argument");
+    int rc;
+    if ((rc = set_device(b->ctx)) != 0) return rc;
+    const Seg &s = b->h_segs[blob];
+    if (n > s.n) n = s.n;
+    if (n) HIP_TRY(hipMemcpy(packed, b->res.as<uint32_t>() + s.off, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mi355_lzss_batch_index(mi355_lzss_batch *b, uint32_t blob, int32_t *sa, int32_t *isa, uint16_t *lcp,
+                                      size_t n_plus_1) {
+    if (!b || blob >= b->n_blobs) return fail(MI355_LZSS_E_ARG, "bad argument");
+    int rc;
+    if ((rc = set_device(b->ctx)) != 0) return rc;
+    const Seg &s = b->h_segs[blob];
+    size_t N = std::min<size_t>(n_plus_1, (size_t)s.n + 1);
+    if (sa) HIP_TRY(hipMemcpy(sa, b->sa.as<int32_t>() + s.off, N * 4, hipMemcpyDeviceToHost));
+    if (isa) HIP_TRY(hipMemcpy(isa, b->isa.as<int32_t>() + s.off, N * 4, hipMemcpyDeviceToHost));
+    if (lcp) HIP_TRY(hipMemcpy(lcp, b->lcp.as<uint16_t>() + s.off, N * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mi355_lzss_batch_stage_times(const mi355_lzss_batch *b, const char **names, float *ms, int cap) {
+    if (!b) return 0;
+    int k = 0;
+    for (; k < ST_COUNT && k < cap; ++k) {
+        if (names) names[k] = kStageNames[k];
+        if (ms) ms[k] = b->stage_ms[k];
+    }
+    return k;
+}
+
+// ---- context ----------------------------------------------------------------------------------------
+extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int device, mi355_lzss_ctx **out) {
+    if (!out || (dict_len && !dict)) return fail(MI355_LZSS_E_ARG, "null argument");
+    *out = nullptr;
+    // AugmentDict, lzss/compress.go:70-88
+    std::vector<uint8_t> aug(dict, dict + dict_len);
+    {
+        uint8_t found = 0;
+        bool both = false;
+        for (size_t i = 0; i < dict_len && !both; ++i) {
+            if (dict[i] == LZSS_SYMBOL_SHORT) found |= 2;
+            else if (dict[i] == LZSS_SYMBOL_DYNAMIC) found |= 4;
+            else continue;
+            both = (found == 6);
+        }
+        if (!both) {
+            aug.push_back(LZSS_SYMBOL_SHORT);
+            aug.push_back(LZSS_SYMBOL_DYNAMIC);
+        }
+    }
+    if (aug.size() > LZSS_MAX_DICT_SIZE)  // compress.go:39-41
+        return fail(MI355_LZSS_E_DICT_SIZE, "dict size must be <= %d", LZSS_MAX_DICT_SIZE);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MI355_LZSS_E_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(MI355_LZSS_E_DEVICE, "device %d out of range (%d devices)", device, ndev);
+
+    mi355_lzss_ctx *ctx = new mi355_lzss_ctx();
+    ctx->device = device;
+    ctx->dict = aug;
+    // dictReservedIdx, compress.go:47-59: last occurrence of each symbol up to the point both were seen
+    {
+        bool fe = false, ff = false;
+        for (size_t i = 0; i < aug.size(); ++i) {
+            if (aug[i] == LZSS_SYMBOL_DYNAMIC) { ctx->res_idx[1] = (int32_t)i; ff = true; }
+            else if (aug[i] == LZSS_SYMBOL_SHORT) { ctx->res_idx[0] = (int32_t)i; fe = true; }
+            else continue;
+            if (fe && ff) break;
+        }
+    }
+    int rc = 0;
+    auto bail = [&](int code) {
+        mi355_lzss_ctx_destroy(ctx);
+        return code;
+    };
+    if ((rc = set_device(ctx)) != 0) return bail(rc);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(MI355_LZSS_E_DEVICE, "hipStreamCreate failed"));
+
+    // dictionary index (compress.go:64) built with the same kernels as the input index
+    mi355_lzss_batch *b = nullptr;
+    if ((rc = mi355_lzss_batch_create(ctx, 1, aug.size(), &b)) != 0) return bail(rc);
+    ctx->scratch = b;
+    const uint64_t off2[2] = {0, aug.size()};
+    if ((rc = mi355_lzss_batch_upload(b, aug.data(), off2, 1, nullptr)) != 0) return bail(rc);
+    launch_sa_build(b->segs.as<Seg>(), 1, b->text.as<uint8_t>(), sa_work(b), ctx->stream);
+    launch_lcp(b->segs.as<Seg>(), 1, b->max_n, batch_index(b), ctx->stream);
+    const size_t stride = (size_t)seg_stride(aug.size());
+    if ((rc = ctx->d_text.ensure(stride)) != 0) return bail(rc);
+    if ((rc = ctx->d_sa.ensure(stride * 4)) != 0) return bail(rc);
+    if ((rc = ctx->d_isa.ensure(stride * 4)) != 0) return bail(rc);
+    if ((rc = ctx->d_lcp.ensure(stride * 2)) != 0) return bail(rc);
+    if ((rc = ctx->d_b1.ensure((stride / 64 + 1) * 2)) != 0) return bail(rc);
+    if ((rc = ctx->d_b2.ensure((stride / 64 + 1) * 2)) != 0) return bail(rc);
+    hipStream_t sm = ctx->stream;
+#define CP(dst, src, bytes)                                                                              \
+    if (hipMemcpyAsync(ctx->dst.p, b->src.p, (bytes), hipMemcpyDeviceToDevice, sm) != hipSuccess)         \
+        return bail(fail(MI355_LZSS_E_DEVICE, "device copy of the dictionary index failed"));
+    CP(d_text, text, stride) CP(d_sa, sa, stride * 4) CP(d_isa, isa, stride * 4) CP(d_lcp, lcp, stride * 2)
+    CP(d_b1, b1, (stride / 64 + 1) * 2) CP(d_b2, b2, (stride / 64 + 1) * 2)
+#undef CP
+    if (hipStreamSynchronize(sm) != hipSuccess || hipGetLastError() != hipSuccess)
+        return bail(fail(MI355_LZSS_E_DEVICE, "building the dictionary index failed: %s", hipGetErrorString(hipGetLastError())));
+    ctx->view.T = ctx->d_text.as<uint8_t>();
+    ctx->view.n = (uint32_t)aug.size();
+    ctx->view.SA = ctx->d_sa.as<int32_t>();
+    ctx->view.LCP = ctx->d_lcp.as<uint16_t>();
+    ctx->view.bmin1 = ctx->d_b1.as<uint16_t>();
+    ctx->view.bmin2 = ctx->d_b2.as<uint16_t>();
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void mi355_lzss_ctx_destroy(mi355_lzss_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->scratch) mi355_lzss_batch_destroy(ctx->scratch);
+    DevBuf *bufs[] = {&ctx->d_text, &ctx->d_sa, &ctx->d_isa, &ctx->d_lcp, &ctx->d_b1, &ctx->d_b2};
+    for (DevBuf *d : bufs) d->release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int mi355_lzss_dict_info(const mi355_lzss_ctx *ctx, uint64_t *aug_len, int32_t reserved_idx[2]) {
+    if (!ctx) return fail(MI355_LZSS_E_ARG, "null argument");
+    if (aug_len) *aug_len = ctx->dict.size();
+    if (reserved_idx) {
+        reserved_idx[0] = ctx->res_idx[0];
+        reserved_idx[1] = ctx->res_idx[1];
+    }
+    return 0;
+}
+
+// ---- single-buffer entry points -----------------------------------------------------------------------
+static int upload_one(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, size_t start) {
+    if (!ctx || (n && !d)) return fail(MI355_LZSS_E_ARG, "null argument");
+    if (n > LZSS_MAX_INPUT_SIZE) return fail(MI355_LZSS_E_INPUT_SIZE, "input size must be <= %d", LZSS_MAX_INPUT_SIZE);
+    if (start > n) return fail(MI355_LZSS_E_ARG, "start beyond the end of the buffer");
+    const uint64_t off2[2] = {0, n};
+    const uint32_t st = (uint32_t)start;
+    return mi355_lzss_batch_upload(ctx->scratch, d ? d : (const uint8_t *)"", off2, 1, &st);
+}
+
+extern "C" int mi355_lzss_best_backrefs(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, size_t start, int32_t *addr,
+                                        int32_t *len, uint8_t *type) {
+    int rc;
+    if ((rc = upload_one(ctx, d, n, start)) != 0) return rc;
+    mi355_lzss_batch *b = ctx->scratch;
+    if ((rc = run_index_and_match(b)) != 0) return rc;
+    std::vector<uint32_t> packed(n ? n : 1);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = mi355_lzss_batch_results(b, 0, packed.data(), n)) != 0) return rc;
+    const int dict_len = (int)ctx->dict.size();
+    for (size_t i = start; i < n; ++i) {
+        const uint32_t r = packed[i];
+        const size_t o = i - start;
+        const uint32_t t = res_type(r);
+        if (t == RES_NONE) {
+            if (type) type[o] = 0;
+            if (addr) addr[o] = -1;
+            if (len) len[o] = -1;
+            continue;
+        }
+        const int field = (int)res_field(r);
+        int a;
+        if (t == RES_SHORT) a = (int)i - field - 1;
+        else a = (int)i + dict_len - field - 1;  // backref.go:66 inverted (dictionary-prefixed address)
+        if (type) type[o] = t == RES_SHORT ? LZSS_SYMBOL_SHORT : LZSS_SYMBOL_DYNAMIC;
+        if (addr) addr[o] = a;
+        if (len) len[o] = (int)res_len(r);
+    }
+    return 0;
+}
+
+extern "C" int mi355_lzss_write(mi355_lzss_ctx *ctx, const uint8_t *inbuf, size_t n, size_t start, unsigned bit_off,
+                                uint8_t *out, size_t out_cap, uint64_t *nbits) {
+    if (bit_off > 7) return fail(MI355_LZSS_E_ARG, "bit_off must be 0..7");
+    int rc;
+    if ((rc = upload_one(ctx, inbuf, n, start)) != 0) return rc;
+    mi355_lzss_batch *b = ctx->scratch;
+    if ((rc = run_index_and_match(b)) != 0) return rc;
+    if ((rc = run_walk_emit(b, 0, bit_off, true)) != 0) return rc;
+    if (nbits) *nbits = b->h_nbits[0];
+    const size_t need = b->h_out_len[0];
+    if (need > out_cap) return fail(MI355_LZSS_E_CAPACITY, "output needs %zu bytes, capacity is %zu", need, out_cap);
+    if (b->h_status[0] != 0) return fail(b->h_status[0], "emit failed with status %d", b->h_status[0]);
+    if (need) HIP_TRY(hipMemcpy(out, b->out.as<uint8_t>() + b->h_out_off[0], need, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mi355_lzss_compressed_size(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, uint64_t *size) {
+    if (n > LZSS_SIZE256K_MAX) return fail(MI355_LZSS_E_INPUT_SIZE, "input size must be <= %d", LZSS_SIZE256K_MAX);
+    int rc;
+    if ((rc = upload_one(ctx, d, n, 0)) != 0) return rc;
+    mi355_lzss_batch *b = ctx->scratch;
+    if ((rc = run_index_and_match(b)) != 0) return rc;
+    if ((rc = run_walk_emit(b, LZSS_HEADER_SIZE, 0, false)) != 0) return rc;
+    if (size) *size = b->h_out_len[0];
+    return 0;
+}
+
+// ---- host-buffer batch ----------------------------------------------------------------------------------
+extern "C" int mi355_lzss_compress_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
+                                         uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
+    if (!ctx || !in_off || !out_off) return fail(MI355_LZSS_E_ARG, "null argument");
+    int rc;
+    mi355_lzss_batch *b = ctx->scratch;
+    if ((rc = mi355_lzss_batch_upload(b, in, in_off, n_blobs, nullptr)) != 0) return rc;
+    if ((rc = mi355_lzss_batch_compress(b, 1)) != 0) return rc;
+    if (out_len)
+        for (uint32_t k = 0; k < n_blobs; ++k) out_len[k] = b->h_out_len[k];
+    return mi355_lzss_batch_download(b, out, out_off, status);
+}
+
+// ---- decompression: see decompress.hip ----------------------------------------------------------------------
+extern "C" int mi355_lzss_decompress_batch(mi355_lzss_ctx *, const uint8_t *, const uint64_t *, uint32_t, uint8_t *,
+                                           const uint64_t *, uint32_t *, int32_t *) {
+    return fail(MI355_LZSS_E_DEVICE, "decompress_batch: not built yet");
+}
+extern "C" int mi355_lzss_batch_upload_compressed(mi355_lzss_batch *, const uint8_t *, const uint64_t *, uint32_t,
+                                                  const uint64_t *) {
+    return fail(MI355_LZSS_E_DEVICE, "decompress_batch: not built yet");
+}
+extern "C" int mi355_lzss_batch_decompress(mi355_lzss_batch *) {
+    return fail(MI355_LZSS_E_DEVICE, "decompress_batch: not built yet");
+}
+extern "C" int mi355_lzss_batch_download_decompressed(mi355_lzss_batch *, uint8_t *, const uint64_t *, uint32_t *, int32_t *) {
+    return fail(MI355_LZSS_E_DEVICE, "decompress_batch: not built yet");
+}

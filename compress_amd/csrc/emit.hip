@@ -1,0 +1,345 @@
+// emit.hip - phrase selection walk and MSB-first bit emission (gfx950).
+//
+// Replaces the main loop of compressor.write (lzss/compress.go:176-257) and backref.writeTo
+// (lzss/backref.go:63-68) / TryWriteByte.
+//
+// The loop `for i := start; i < n; i += advance(i)` is a chain, but advance(i) and the phrase chosen
+// at i are pure functions of the position (the RLE test compress.go:180-184, bestBackref at i, i+1,
+// i+2).  So:
+//   decide_kernel   every position in parallel: phrase kind + advance (<= 256);
+//   walk_kernel     one workgroup per blob; because advance <= 256 the chain never skips a 256-position
+//                   tile, so (A) every tile resolves "enter at e -> leave at x" for all its entries
+//                   backwards, (B) one lane hops tile to tile, (C) every tile walks its own part of
+//                   the chain and sums phrase bits; a scan gives each tile its bit offset;
+//   emit_kernel     every tile packs its phrases into bytes; the two partial bytes at a tile's ends are
+//                   merged with the neighbours' after a barrier (no atomics).
+#include "kernels.h"
+
+namespace lzss {
+
+constexpr int DECIDE_THREADS = 256;
+constexpr int WALK_THREADS = 512;
+constexpr int TILE = 256;  // must be >= the largest advance (1 << maxBackrefLenLog2)
+
+__device__ inline int savings_of(uint32_t r) {  // backref.savings, lzss/backref.go:88-93
+    const uint32_t t = res_type(r);
+    if (t == RES_NONE) return INT_MIN / 2;
+    return 8 * (int)res_len(r) - (t == RES_SHORT ? LZSS_SHORT_BITS : LZSS_DYN_BITS);
+}
+
+__global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs, const uint8_t *text, const uint32_t *res,
+                                                                uint8_t *adv_out, uint8_t *kind_out) {
+    const Seg sg = segs[blockIdx.y];
+    const int n = (int)sg.n;
+    const int i = (int)(blockIdx.x * DECIDE_THREADS + threadIdx.x);
+    if (i >= n || i < (int)sg.start) return;
+    const uint8_t *T = text + sg.off;
+    const uint32_t *R = res + sg.off;
+    const uint8_t c = T[i];
+    const bool reserved = c >= LZSS_SYMBOL_SHORT;
+
+    // run of equal bytes starting at i, capped at 256 and at the end of the buffer (compress.go:180-183)
+    const int lim = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
+    int count = 0;
+    {
+        const uint64_t pat = 0x0101010101010101ull * c;
+        while (count < lim) {
+            const uint64_t x = ld8(T + i + count) ^ pat;
+            if (x) {
+                count += (int)(__builtin_ctzll(x) >> 3);
+                break;
+            }
+            count += 8;
+        }
+        if (count > lim) count = lim;
+    }
+    int advance;
+    uint8_t kind;
+    if (count >= LZSS_MIN_REPEAT) {  // compress.go:184-218
+        advance = count;
+        if (i > 0 && T[i - 1] == c) kind = K_RLE_CONT;
+        else kind = reserved ? K_RLE_RES : K_RLE_LIT;
+    } else {
+        const uint32_t r0 = R[i];
+        const int s0 = savings_of(r0);
+        const uint8_t refkind = res_type(r0) == RES_SHORT ? K_SHORT : K_DYN;
+        if (reserved) {  // compress.go:221-226 (a dictionary reference of length 1 always exists)
+            kind = refkind;
+            advance = (int)res_len(r0);
+            if (res_type(r0) == RES_NONE) { kind = K_LIT; advance = 1; }  // unreachable; keeps the chain finite
+        } else if (s0 < 0) {  // compress.go:227-232
+            kind = K_LIT;
+            advance = 1;
+        } else if (i + 1 < n && savings_of(R[i + 1]) > s0 + 1) {  // compress.go:235-242
+            kind = K_LIT;
+            advance = 1;
+        } else if (i + 2 < n && T[i + 1] < LZSS_SYMBOL_SHORT && savings_of(R[i + 2]) > s0 + 2) {  // :243-253
+            kind = K_LIT2;
+            advance = 2;
+        } else {  // compress.go:255-256
+            kind = refkind;
+            advance = (int)res_len(r0);
+        }
+    }
+    adv_out[sg.off + i] = (uint8_t)(advance - 1);
+    kind_out[sg.off + i] = kind;
+}
+
+void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint32_t *d_res,
+                   const WalkWork &ww, hipStream_t stream) {
+    if (n_segs == 0 || max_n == 0) return;
+    dim3 g((max_n + DECIDE_THREADS - 1) / DECIDE_THREADS, n_segs);
+    hipLaunchKernelGGL(decide_kernel, g, dim3(DECIDE_THREADS), 0, stream, d_segs, d_text, d_res, ww.adv, ww.kind);
+}
+
+// ---- walk: visited tiles, per-tile bit offsets, per-blob size -------------------------------------
+__global__ __launch_bounds__(WALK_THREADS) void walk_kernel(const Seg *segs, WalkWork ww, uint32_t header_bytes,
+                                                            uint32_t bit_off) {
+    __shared__ uint64_t s_wave[WALK_THREADS / 64];
+    __shared__ uint64_t s_carry;
+    const Seg sg = segs[blockIdx.x];
+    const int n = (int)sg.n, start = (int)sg.start;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint8_t *adv = ww.adv + sg.off;
+    const uint8_t *kind = ww.kind + sg.off;
+    uint8_t *exitoff = ww.exitoff + sg.off;
+    uint16_t *entry = ww.entry + sg.off / TILE;
+    uint64_t *tilebit = ww.tilebit + sg.off / TILE;
+    const int ntiles = (n + TILE - 1) / TILE;
+    const int t0 = start / TILE;
+
+    // (A) for every position: where the chain from it first lands beyond its tile
+    for (int t = t0 + tid; t < ntiles; t += WALK_THREADS) {
+        const int tend = (t + 1) * TILE;
+        const int hi = tend < n ? tend : n;
+        const int lo = t * TILE > start ? t * TILE : start;
+        for (int i = hi - 1; i >= lo; --i) {
+            const int nx = i + (int)adv[i] + 1;
+            uint8_t e;
+            if (nx >= tend) e = (uint8_t)(nx - tend);
+            else if (nx >= n) e = 0;
+            else e = exitoff[nx];
+            exitoff[i] = e;
+        }
+        entry[t] = 0xFFFFu;
+    }
+    __syncthreads();
+    // (B) hop from tile to tile
+    if (tid == 0 && start < n) {
+        int e = start;
+        for (int t = t0;; ++t) {
+            entry[t] = (uint16_t)(e - t * TILE);
+            if (t + 1 >= ntiles) break;
+            e = (t + 1) * TILE + (int)exitoff[e];
+            if (e >= n) break;
+        }
+    }
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    // (C) bits per tile, exclusive scan in tile order
+    for (int tb = t0; tb < ntiles; tb += WALK_THREADS) {
+        const int t = tb + tid;
+        uint64_t bits = 0;
+        if (t < ntiles) {
+            const uint32_t e = entry[t];
+            if (e != 0xFFFFu) {
+                const int tend = (t + 1) * TILE;
+                const int hi = tend < n ? tend : n;
+                for (int i = t * TILE + (int)e; i < hi; i += (int)adv[i] + 1) bits += kind_bits(kind[i]);
+            }
+        }
+        uint64_t inc = bits;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) s_wave[w] = inc;
+        __syncthreads();
+        uint64_t base = s_carry;
+        for (int ww2 = 0; ww2 < w; ++ww2) base += s_wave[ww2];
+        if (t < ntiles) tilebit[t] = (uint64_t)bit_off + base + inc - bits;
+        __syncthreads();
+        if (tid == WALK_THREADS - 1) s_carry = base + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint64_t total = s_carry;
+        ww.nbits[blockIdx.x] = total;
+        ww.out_len[blockIdx.x] = header_bytes + (uint32_t)(((uint64_t)bit_off + total + 7) / 8);
+    }
+}
+
+void launch_walk(const Seg *d_segs, uint32_t n_segs, const WalkWork &ww, uint32_t header_bytes, uint32_t bit_off,
+                 hipStream_t stream) {
+    if (n_segs == 0) return;
+    hipLaunchKernelGGL(walk_kernel, dim3(n_segs), dim3(WALK_THREADS), 0, stream, d_segs, ww, header_bytes, bit_off);
+}
+
+// ---- output offsets: exclusive scan of the 16-byte aligned blob sizes -----------------------------
+__global__ __launch_bounds__(1024) void out_offsets_kernel(uint32_t n_segs, WalkWork ww) {
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_segs; b0 += 1024) {
+        const uint32_t b = b0 + tid;
+        const uint64_t v = b < n_segs ? (((uint64_t)ww.out_len[b] + 15) & ~15ull) : 0;
+        uint64_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t x = __shfl_up(inc, o);
+            if (lane >= o) inc += x;
+        }
+        if (lane == 63) s_wave[w] = inc;
+        __syncthreads();
+        uint64_t base = s_carry;
+        for (int k = 0; k < w; ++k) base += s_wave[k];
+        if (b < n_segs) ww.out_off[b] = base + inc - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = base + inc;
+        __syncthreads();
+    }
+    if (tid == 0) ww.out_off[n_segs] = s_carry;
+}
+
+void launch_out_offsets(uint32_t n_segs, const WalkWork &ww, hipStream_t stream) {
+    hipLaunchKernelGGL(out_offsets_kernel, dim3(1), dim3(1024), 0, stream, n_segs, ww);
+}
+
+// ---- emit -------------------------------------------------------------------------------------------
+struct BitSink {
+    uint8_t *out;     // byte 0 of the blob's phrase stream
+    uint64_t pos;     // next byte index
+    uint64_t acc;     // pending bits, right aligned
+    int na;           // number of pending bits
+    bool first;       // the next flushed byte is shared with the previous tile
+    uint8_t head;
+    __device__ inline void put(uint64_t v, int nb) {
+        acc = (acc << nb) | v;
+        na += nb;
+        while (na >= 8) {
+            const uint8_t byte = (uint8_t)(acc >> (na - 8));
+            na -= 8;
+            if (first) { head = byte; first = false; }
+            else out[pos] = byte;
+            ++pos;
+        }
+        acc &= (1ull << na) - 1ull;
+    }
+};
+
+__global__ __launch_bounds__(WALK_THREADS) void emit_kernel(const Seg *segs, const uint8_t *text, const uint32_t *res,
+                                                            WalkWork ww, uint32_t header_bytes, uint32_t bit_off,
+                                                            uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
+                                                            uint8_t *out_buf, uint64_t out_cap, int32_t *status) {
+    const Seg sg = segs[blockIdx.x];
+    const int n = (int)sg.n, start = (int)sg.start;
+    const int tid = threadIdx.x;
+    const uint64_t ooff = ww.out_off[blockIdx.x];
+    const uint32_t olen = ww.out_len[blockIdx.x];
+    if (ooff + olen > out_cap) {
+        if (tid == 0) status[blockIdx.x] = -5;  // MI355_LZSS_E_CAPACITY
+        return;
+    }
+    if (tid == 0) status[blockIdx.x] = 0;
+    const uint8_t *T = text + sg.off;
+    const uint32_t *R = res + sg.off;
+    const uint8_t *adv = ww.adv + sg.off;
+    const uint8_t *kind = ww.kind + sg.off;
+    const uint16_t *entry = ww.entry + sg.off / TILE;
+    const uint64_t *tilebit = ww.tilebit + sg.off / TILE;
+    uint8_t *headb = ww.headb + sg.off / TILE;
+    uint8_t *tailb = ww.tailb + sg.off / TILE;
+    uint8_t *out = out_buf + ooff;
+    if (tid == 0 && header_bytes == LZSS_HEADER_SIZE) {  // lzss/header.go:22-32, NoCompression = false
+        out[0] = (uint8_t)(LZSS_VERSION >> 8);
+        out[1] = (uint8_t)(LZSS_VERSION & 0xFF);
+        out[2] = 0;
+    }
+    out += header_bytes;
+    const int ntiles = (n + TILE - 1) / TILE;
+    const int t0 = start / TILE;
+    if (start >= n) {  // empty Write: only the (zero) partial byte, if any
+        if (tid == 0 && bit_off != 0) out[0] = 0;
+        return;
+    }
+
+    for (int t = t0 + tid; t < ntiles; t += WALK_THREADS) {
+        const uint32_t e = entry[t];
+        if (e == 0xFFFFu) continue;
+        const uint64_t b0 = tilebit[t];
+        BitSink s;
+        s.out = out;
+        s.pos = b0 >> 3;
+        s.acc = 0;
+        s.na = (int)(b0 & 7);
+        s.first = (b0 & 7) != 0;
+        s.head = 0;
+        const int tend = (t + 1) * TILE;
+        const int hi = tend < n ? tend : n;
+        for (int i = t * TILE + (int)e; i < hi;) {
+            const uint8_t k = kind[i];
+            const int a = (int)adv[i] + 1;
+            switch (k) {
+                case K_LIT: s.put(T[i], 8); break;
+                case K_LIT2: s.put(((uint64_t)T[i] << 8) | T[i + 1], 16); break;
+                case K_SHORT: {
+                    const uint32_t r = R[i];
+                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(res_len(r) - 1) << 14) | (res_field(r) & 0x3FFFu),
+                          LZSS_SHORT_BITS);
+                    break;
+                }
+                case K_DYN: {
+                    const uint32_t r = R[i];
+                    s.put(((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | ((uint64_t)(res_len(r) - 1) << 21) | res_field(r), LZSS_DYN_BITS);
+                    break;
+                }
+                case K_RLE_CONT:  // short ref at address i-1, length count (compress.go:209-212)
+                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(a - 1) << 14), LZSS_SHORT_BITS);
+                    break;
+                case K_RLE_LIT:  // the byte itself, then a short ref of length count-1 (compress.go:201-212)
+                    s.put(T[i], 8);
+                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(a - 2) << 14), LZSS_SHORT_BITS);
+                    break;
+                default: {  // K_RLE_RES: length-1 reference to the reserved symbol in the dictionary (compress.go:192-200)
+                    const int idx = T[i] == LZSS_SYMBOL_DYNAMIC ? res_idx_ff : res_idx_fe;
+                    const uint64_t field = (uint64_t)((uint32_t)(i + (int)dict_len - idx - 1) & 0x1FFFFFu);
+                    s.put(((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | field, LZSS_DYN_BITS);
+                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(a - 2) << 14), LZSS_SHORT_BITS);
+                    break;
+                }
+            }
+            i += a;
+        }
+        headb[t] = s.head;
+        tailb[t] = s.na ? (uint8_t)(s.acc << (8 - s.na)) : 0;
+    }
+    __syncthreads();
+    // merge the partial bytes at tile seams; the last visited tile writes the zero-padded final byte
+    for (int t = t0 + tid; t < ntiles; t += WALK_THREADS) {
+        if (entry[t] == 0xFFFFu) continue;
+        const uint64_t b0 = tilebit[t];
+        if (b0 & 7) {
+            uint8_t v = headb[t];
+            if (t > t0) v |= tailb[t - 1];
+            out[b0 >> 3] = v;
+        }
+        const bool last = (t + 1 >= ntiles) || entry[t + 1] == 0xFFFFu;
+        if (last) {
+            const uint64_t b1 = (uint64_t)bit_off + ww.nbits[blockIdx.x];
+            if (b1 & 7) out[b1 >> 3] = tailb[t];
+        }
+    }
+}
+
+void launch_emit(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const uint32_t *d_res, const WalkWork &ww,
+                 uint32_t header_bytes, uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
+                 uint8_t *d_out, uint64_t out_cap, int32_t *d_status, hipStream_t stream) {
+    if (n_segs == 0) return;
+    hipLaunchKernelGGL(emit_kernel, dim3(n_segs), dim3(WALK_THREADS), 0, stream, d_segs, d_text, d_res, ww, header_bytes,
+                       bit_off, dict_len, res_idx_fe, res_idx_ff, d_out, out_cap, d_status);
+}
+
+}  // namespace lzss

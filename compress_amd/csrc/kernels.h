@@ -1,0 +1,57 @@
+// kernels.h - launchers of the HIP kernels (internal to libmi355_lzss.so).
+#pragma once
+#include "lzss_device.h"
+
+namespace lzss {
+
+// ---- sa_build.hip -----------------------------------------------------------------------------
+struct SaWork {       // batch-wide arrays, indexed [seg.off + k], k in [0, n]
+    int32_t *keyA, *valA, *keyB, *valB;  // radix-sort ping-pong (rank key, suffix)
+    int32_t *rkA, *rkB;                  // group ranks, double buffered
+    uint8_t *flags;                      // group-boundary flags
+    int32_t *sa, *isa;                   // outputs
+};
+void launch_sa_build(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const SaWork &wk, hipStream_t stream);
+
+// ---- match.hip --------------------------------------------------------------------------------
+struct DictView {     // the dictionary index of a ctx (device pointers)
+    const uint8_t *T;
+    uint32_t n;
+    const int32_t *SA;
+    const uint16_t *LCP, *bmin1, *bmin2;
+};
+struct BatchIndex {   // batch-wide index arrays
+    const uint8_t *text;
+    int32_t *sa, *isa;
+    uint16_t *lcp;    // [seg.off + k]
+    uint16_t *bmin1;  // [seg.off/64 + k/64]
+    uint16_t *bmin2;  // [seg.off/64 + k/4096]
+};
+void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream);
+void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
+                  uint32_t *d_res, hipStream_t stream);
+
+// ---- emit.hip ---------------------------------------------------------------------------------
+struct WalkWork {
+    uint8_t *adv;       // [seg.off + i]  advance - 1 of the phrase chosen at i
+    uint8_t *kind;      // [seg.off + i]  phrase kind
+    uint8_t *exitoff;   // [seg.off + i]  where the chain from i first lands past i's 256-tile
+    uint16_t *entry;    // [seg.off/256 + t] offset of the first visited position in tile t, 0xFFFF = none
+    uint64_t *tilebit;  // [seg.off/256 + t] bit offset of tile t's first phrase in the blob's stream
+    uint8_t *headb;     // [seg.off/256 + t] tile t's share of the byte it shares with tile t-1
+    uint8_t *tailb;     // [seg.off/256 + t] tile t's share of the byte it shares with tile t+1
+    uint64_t *nbits;    // [seg] phrase bits of the blob
+    uint64_t *out_off;  // [seg], n_segs+1 entries: byte offset of the blob's output in the batch output buffer
+    uint32_t *out_len;  // [seg] bytes written (header + ceil(bits/8))
+};
+void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint32_t *d_res,
+                   const WalkWork &ww, hipStream_t stream);
+// header_bytes: 3 (one-shot Compress) or 0; bit_off: first bit of the stream inside its first byte (streaming Write)
+void launch_walk(const Seg *d_segs, uint32_t n_segs, const WalkWork &ww, uint32_t header_bytes, uint32_t bit_off,
+                 hipStream_t stream);
+void launch_out_offsets(uint32_t n_segs, const WalkWork &ww, hipStream_t stream);
+void launch_emit(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const uint32_t *d_res, const WalkWork &ww,
+                 uint32_t header_bytes, uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
+                 uint8_t *d_out, uint64_t out_cap, int32_t *d_status, hipStream_t stream);
+
+}  // namespace lzss

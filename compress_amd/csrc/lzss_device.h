@@ -1,0 +1,119 @@
+// lzss_device.h - data layout shared by the HIP kernels and the C-ABI host code (gfx950 only).
+//
+// A *segment* is one indexed text: a blob's whole inBuf (lzss/compress.go:113-116) or the augmented
+// dictionary (compress.go:64).  All per-position arrays of a segment live at the same element offset
+// `off` inside batch-wide arrays, so one launch covers every blob of a batch.
+//
+// Index arrays are in the "N-world": N = n + 1 entries, rank 0 is the implicit end sentinel of
+// suffixarray.New (a suffix that is a prefix of another sorts first), i.e. SA[0] == n and the
+// reference's suffix array is SA[1..N).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lzss_format.h"
+
+namespace lzss {
+
+struct Seg {
+    uint64_t off;    // element offset of this segment in every per-position array (multiple of 256)
+    uint32_t n;      // text length in bytes
+    uint32_t start;  // first position to encode (Write's lastInLen, compress.go:118)
+};
+
+constexpr uint32_t SEG_ALIGN = 256;   // segment stride granularity; >= 16 bytes of zero padding follow each text
+constexpr uint32_t SEG_PAD = 64;      // stride = align(n + SEG_PAD)
+constexpr int HEAD = 512;             // positions below HEAD are matched by brute force (match_head_kernel)
+
+// packed per-position result of bestBackref (compress.go:146-173)
+constexpr uint32_t RES_NONE = 0u;
+constexpr uint32_t RES_SHORT = 1u;
+constexpr uint32_t RES_DYN = 2u;
+__host__ __device__ inline uint32_t res_pack(uint32_t type, uint32_t len, uint32_t field) {
+    return (type << 30) | (len << 21) | (field & 0x1FFFFFu);
+}
+__host__ __device__ inline uint32_t res_type(uint32_t r) { return r >> 30; }
+__host__ __device__ inline uint32_t res_len(uint32_t r) { return (r >> 21) & 0x1FFu; }
+__host__ __device__ inline uint32_t res_field(uint32_t r) { return r & 0x1FFFFFu; }
+
+// phrase kinds chosen by the walk (compress.go:176-257)
+enum : uint8_t {
+    K_LIT = 0,        // one literal                               8 bits
+    K_LIT2 = 1,       // two literals (lookahead at i+2)           16 bits
+    K_SHORT = 2,      // short back-reference                      30 bits
+    K_DYN = 3,        // long back-reference                       37 bits
+    K_RLE_CONT = 4,   // RLE, previous byte equal: short ref off 0 30 bits
+    K_RLE_LIT = 5,    // RLE: literal + short ref                  38 bits
+    K_RLE_RES = 6,    // RLE of a reserved symbol: dict ref + short ref  67 bits
+};
+__host__ __device__ inline uint32_t kind_bits(uint8_t k) {
+    switch (k) {
+        case K_LIT: return 8;
+        case K_LIT2: return 16;
+        case K_SHORT: return LZSS_SHORT_BITS;
+        case K_DYN: return LZSS_DYN_BITS;
+        case K_RLE_CONT: return LZSS_SHORT_BITS;
+        case K_RLE_LIT: return 8 + LZSS_SHORT_BITS;
+        default: return LZSS_DYN_BITS + LZSS_SHORT_BITS;
+    }
+}
+
+// suffix-array index of one text as the match kernels see it
+struct IndexView {
+    const uint8_t *T;       // text, readable 16 bytes past n
+    uint32_t n;             // text length; N = n + 1
+    const int32_t *SA;      // N entries
+    const int32_t *ISA;     // N entries (rank of every suffix)
+    const uint16_t *LCP;    // N entries, LCP[k] = lcp(SA[k-1], SA[k]) capped at 256; LCP[0] = 0
+    const uint16_t *bmin1;  // min of LCP over blocks of 64 ranks
+    const uint16_t *bmin2;  // min of bmin1 over blocks of 64 blocks
+};
+
+// 8 bytes at any byte address (amdhsa runs with unaligned access enabled)
+__device__ inline uint64_t ld8(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// common prefix length of a and b starting from `from`, at most lim; both readable 8 bytes past lim
+__device__ inline int lcp_bytes(const uint8_t *a, const uint8_t *b, int from, int lim) {
+    int o = from;
+    while (o < lim) {
+        uint64_t x = ld8(a + o) ^ ld8(b + o);
+        if (x) {
+            o += (int)(__builtin_ctzll(x) >> 3);
+            break;
+        }
+        o += 8;
+    }
+    return o < lim ? o : lim;
+}
+
+// largest j <= k with LCP[j] < L (L >= 1; LCP[0] == 0 guarantees one exists): the first rank of
+// the interval of suffixes sharing >= L bytes with the suffix of rank k.
+__device__ inline int prev_lower(const uint16_t *LCP, const uint16_t *bmin1, const uint16_t *bmin2, int k, int L) {
+    int j = k;
+    for (;;) {
+        if ((int)LCP[j] < L) return j;
+        if ((j & 63) == 0) break;
+        --j;
+    }
+    if (j == 0) return 0;  // cannot happen (LCP[0] == 0 < L); keeps every loop below bounded
+    int b = (j >> 6) - 1;  // j is a block start with LCP[j] >= L, so j >= 64 here
+    while (b > 0) {
+        if ((int)bmin1[b] < L) break;
+        if ((b & 63) == 0) {
+            int c = (b >> 6) - 1;
+            while (c > 0 && (int)bmin2[c] >= L) --c;
+            b = c * 64 + 63;
+            continue;
+        }
+        --b;
+    }
+    j = b * 64 + 63;
+    while (j > 0 && (int)LCP[j] >= L) --j;
+    return j;
+}
+
+}  // namespace lzss

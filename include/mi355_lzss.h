@@ -1,0 +1,126 @@
+/* mi355_lzss.h - C ABI of the MI355X-native lzss match-finding path.
+ *
+ * This is the drop-in boundary.  The reference (Consensys/compress, pure Go) has no FFI seam;
+ * the seam is its Go package API (lzss/compress.go, lzss/decompress.go).  A Go shim keeps that
+ * API (go/lzss/) and binds the entry points below through cgo.  Every entry
+ * point cites the reference code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every host buffer and the library never keeps
+ *    a host pointer after the call returns (cgo pointer rules);
+ *  - return value: 0 = MI355_LZSS_OK, negative = error; mi355_lzss_last_error() gives the text.
+ *    Where the reference has an error text, the same text is used
+ *    ("dict size must be <= 4194304", "input size must be <= 4194304");
+ *  - a ctx / batch is NOT thread-safe (like lzss.Compressor); use one per thread / goroutine.
+ *    Objects created on different devices are independent;
+ *  - there is no CPU fallback: without a usable HIP device every entry point fails with
+ *    MI355_LZSS_E_DEVICE.
+ */
+#ifndef MI355_LZSS_H
+#define MI355_LZSS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_LZSS_OK            0
+#define MI355_LZSS_E_ARG        -1   /* bad argument */
+#define MI355_LZSS_E_DICT_SIZE  -2   /* "dict size must be <= %d"  lzss/compress.go:39-41 */
+#define MI355_LZSS_E_INPUT_SIZE -3   /* "input size must be <= %d" lzss/compress.go:473-475 */
+#define MI355_LZSS_E_DEVICE     -4   /* HIP runtime error / no device */
+#define MI355_LZSS_E_CAPACITY   -5   /* caller's output buffer too small */
+#define MI355_LZSS_E_FORMAT     -6   /* malformed compressed stream (per blob: see status[]) */
+
+typedef struct mi355_lzss_ctx mi355_lzss_ctx;     /* one dictionary on one device */
+typedef struct mi355_lzss_batch mi355_lzss_batch; /* device workspace for batches of blobs */
+
+/* ---- dictionary / context -------------------------------------------------------------------
+ * Replaces the dictionary half of NewCompressor (lzss/compress.go:37-67): AugmentDict
+ * (compress.go:70-88), the size check (:39-41), dictReservedIdx (:47-59) and
+ * suffixarray.New(dict) (:64) - the dictionary index is built on the device. */
+int  mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int device, mi355_lzss_ctx **out);
+void mi355_lzss_ctx_destroy(mi355_lzss_ctx *ctx);
+/* last error text of this thread (valid until the next failing call on the thread) */
+const char *mi355_lzss_last_error(void);
+/* length of the augmented dictionary and the two reserved-symbol indices ([0]=0xFE, [1]=0xFF) */
+int  mi355_lzss_dict_info(const mi355_lzss_ctx *ctx, uint64_t *aug_len, int32_t reserved_idx[2]);
+
+/* ---- the hot path, one input buffer ----------------------------------------------------------
+ * Per-position results of the bestBackref closure (lzss/compress.go:146-173 = findBackRef
+ * :435-470 over suffixarray.LookupLongest, suffixarray.go:59-152) for every position of
+ * d[start:n); the index covers all of d[0:n) exactly as in Write (compress.go:113-118).
+ * type[k] = 0xFE / 0xFF, or 0 when there is no back-reference; addr = backref.address
+ * (dictionary-prefixed for 0xFF), len = backref.length; arrays hold n-start entries. */
+int mi355_lzss_best_backrefs(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, size_t start,
+                             int32_t *addr, int32_t *len, uint8_t *type);
+
+/* The phrase stream of one Write: compressor.write (lzss/compress.go:138-260) with the bit
+ * emission of backref.writeTo (lzss/backref.go:63-68) for inbuf[start:n), index over inbuf[0:n).
+ * Bits are packed MSB-first starting at bit `bit_off` (0..7) of out[0]; the bit_off high bits of
+ * out[0] are written as zero (the caller ORs its pending partial byte in), the pad bits after
+ * the last phrase are zero.  *nbits = number of phrase bits (without bit_off).
+ * Needs out_cap >= ceil((bit_off + *nbits)/8); on MI355_LZSS_E_CAPACITY *nbits is still set. */
+int mi355_lzss_write(mi355_lzss_ctx *ctx, const uint8_t *inbuf, size_t n, size_t start,
+                     unsigned bit_off, uint8_t *out, size_t out_cap, uint64_t *nbits);
+
+/* CompressedSize256k (lzss/compress.go:384-407): 3 + ceil(bits/8) of write(d, 0); n <= 256 KiB */
+int mi355_lzss_compressed_size(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, uint64_t *size);
+
+/* ---- batches of independent blobs ------------------------------------------------------------
+ * One-shot Compress (lzss/compress.go:375-379 = Reset + Write + Bytes) of n_blobs independent
+ * inputs that share the ctx dictionary.  in_off / out_off are CSR-style byte offsets with
+ * n_blobs+1 entries; blob b is in[in_off[b]:in_off[b+1]) and may use out[out_off[b]:out_off[b+1]).
+ * out_len[b] = compressed size including the 3-byte header; status[b] = 0 or a negative code. */
+int mi355_lzss_compress_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off,
+                              uint32_t n_blobs, uint8_t *out, const uint64_t *out_off,
+                              uint32_t *out_len, int32_t *status);
+
+/* Decompress (lzss/decompress.go:17-84) of n_blobs independent streams with the ctx dictionary.
+ * out_len[b] = decompressed size; status[b] = 0, MI355_LZSS_E_FORMAT or MI355_LZSS_E_CAPACITY. */
+int mi355_lzss_decompress_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off,
+                                uint32_t n_blobs, uint8_t *out, const uint64_t *out_off,
+                                uint32_t *out_len, int32_t *status);
+
+/* ---- device-resident batches (what bench.py times) -------------------------------------------
+ * The same two operations split into upload / run / download so that a caller can keep inputs
+ * and outputs resident in HBM and time the device work alone.  A batch owns all device memory
+ * for up to max_blobs blobs and max_total_bytes input bytes (compress) or output bytes
+ * (decompress).  No counterpart in the reference (it has no device). */
+int  mi355_lzss_batch_create(mi355_lzss_ctx *ctx, uint32_t max_blobs, uint64_t max_total_bytes,
+                             mi355_lzss_batch **out);
+void mi355_lzss_batch_destroy(mi355_lzss_batch *b);
+/* host -> HBM: the blobs to compress (starts[b] = first position to encode, NULL = all zero) */
+int  mi355_lzss_batch_upload(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *in_off,
+                             uint32_t n_blobs, const uint32_t *starts);
+/* device only: index build, match search, phrase walk, bit emission; returns after the stream
+ * has drained.  with_header != 0 writes the 3-byte header in front of every stream. */
+int  mi355_lzss_batch_compress(mi355_lzss_batch *b, int with_header);
+/* sizes of the last run: out_len[b] bytes (incl. header if requested), total = sum */
+int  mi355_lzss_batch_sizes(mi355_lzss_batch *b, uint32_t *out_len, uint64_t *nbits, uint64_t *total);
+/* HBM -> host: compressed blobs into out[out_off[b]:out_off[b+1]) */
+int  mi355_lzss_batch_download(mi355_lzss_batch *b, uint8_t *out, const uint64_t *out_off,
+                               int32_t *status);
+/* per-position results of the last run for blob `blob` (packed: bits 30-31 type (1 short,
+ * 2 long), bits 21-29 length, bits 0-20 offset field); n entries */
+int  mi355_lzss_batch_results(mi355_lzss_batch *b, uint32_t blob, uint32_t *packed, size_t n);
+/* suffix array / inverse / lcp of blob `blob` from the last run (diagnostics for parity tests;
+ * n+1 entries each: rank 0 is the end sentinel) */
+int  mi355_lzss_batch_index(mi355_lzss_batch *b, uint32_t blob, int32_t *sa, int32_t *isa,
+                            uint16_t *lcp, size_t n_plus_1);
+
+/* batched decompression, device resident */
+int  mi355_lzss_batch_upload_compressed(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *in_off,
+                                        uint32_t n_blobs, const uint64_t *out_cap_off);
+int  mi355_lzss_batch_decompress(mi355_lzss_batch *b);
+int  mi355_lzss_batch_download_decompressed(mi355_lzss_batch *b, uint8_t *out, const uint64_t *out_off,
+                                            uint32_t *out_len, int32_t *status);
+
+/* HIP-event time (ms) the stages of the last batch_compress / batch_decompress spent on the
+ * batch's stream; names[k] points to static strings.  Returns the number of stages. */
+int  mi355_lzss_batch_stage_times(const mi355_lzss_batch *b, const char **names, float *ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,82 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/mi355_lzss.h declares; without a
+GPU the product path fails loudly instead of falling back to any CPU code."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mi355_lzss.h")).read()
+    return sorted(set(re.findall(r"\b(mi355_lzss_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from compress_amd import _lib
+    l = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(l, s), s
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_product_does_not_reference_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "compress_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("oracle_lib", "lzss_oracle", "liblzss_oracle", "oracle/", "import oracle", "ora_"):
+                    assert needle not in text, (f, needle)
+    out = subprocess.run(["ldd", os.path.join(ROOT, "compress_amd", "libmi355_lzss.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import compress_amd
+    with pytest.raises(compress_amd.LzssError, match="no HIP device|hip"):
+        compress_amd.Compressor(b"")
+
+
+def test_host_logic_without_device():
+    import compress_amd
+    assert compress_amd.AugmentDict(b"") == b"\xfe\xff"
+    assert compress_amd.AugmentDict(b"\xffa\xfe") == b"\xffa\xfe"
+    h = compress_amd.Header.from_bytes(b"\x00\x01\x01")
+    assert (h.Version, h.NoCompression) == (1, True)
+    assert compress_amd.Header(1, False).to_bytes() == b"\x00\x01\x00"
+    with pytest.raises(compress_amd.LzssError, match="expected 0 or 1"):
+        compress_amd.Header.from_bytes(b"\x00\x01\x02")
+    with pytest.raises(compress_amd.LzssError, match="dict size must be <= 4194304"):
+        compress_amd.Compressor(bytes((1 << 22) - 1))
+
+
+def test_synth_statistics():
+    """SURVEY.md Appendix C acceptance: calldata-like byte statistics, every phrase kind in blob 0"""
+    import numpy as np
+    import oracle_lib as O
+    from compress_amd import synth
+    dict_ = synth.dictionary()
+    assert len(dict_) == 65536
+    c = O.Compressor(dict_)
+    for b in range(3):
+        d = synth.blob(b)
+        assert len(d) == 131072
+        a = np.frombuffer(d, np.uint8)
+        assert 0.55 <= (a == 0).mean() <= 0.72
+        assert 0.003 <= (a == 255).mean() <= 0.03
+        out = c.compress(d)
+        st = c.phrase_stats()
+        assert 3 <= len(d) / len(out) <= 9
+        assert st["rle"] >= 1
+        if b == 0:
+            assert min(st["literals"], st["short"], st["long_data"], st["long_dict"], st["rle"]) > 0
+    assert synth.blob(0) == synth.blob(0) and synth.blob(0) != synth.blob(1)

@@ -1,0 +1,190 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs.  Bar: bit-exact (integer / byte / index work)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import fixture_bytes
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import compress_amd
+    from compress_amd import batch, synth
+    compress_amd.batch = batch
+    compress_amd.synth = synth
+    return compress_amd
+
+
+def rand_cases():
+    rng = np.random.default_rng(42)
+    cases = [b"", b"a", b"hi", bytes(8), bytes(300), b"hihihi", bytes([0xFD, 0xFE, 0xFF]), bytes([1, 1, 1, 1, 2, 1, 1, 1, 1]),
+             b"\x01" + bytes(8), b"hi" + bytes(300), bytes([0xFF]) * 400, bytes([0xFE]) * 170 + b"x" + bytes([0xFE]) * 200,
+             b"abc" * 500, bytes(1000) + b"\x07" + bytes(700)]
+    for k in (1, 2, 3, 4, 256):
+        for n in (5, 63, 64, 65, 257, 1000, 5000):
+            cases.append(bytes(rng.integers(0, k, n, dtype=np.uint8)))
+    cases.append(bytes(rng.choice(np.array([0, 0, 0, 0xFE, 0xFF, 9], dtype=np.uint8), 3000)))
+    return cases
+
+
+def test_index_matches_oracle(amd):
+    """suffix array / inverse / lcp of every blob of a ragged batch (suffixarray.go:32-45)"""
+    cases = rand_cases() + [fixture_bytes("3c2943_data.bin"), amd.synth.blob(0)[:40000]]
+    ctx = amd.batch.new_ctx(b"")
+    b = amd.batch.Batch(ctx, len(cases), sum(map(len, cases)))
+    b.upload(cases)
+    b.compress()
+    for k, d in enumerate(cases):
+        n = len(d)
+        sa, isa, lcp = b.index(k)
+        ref = O.suffix_array(d)
+        assert sa[0] == n
+        assert np.array_equal(sa[1:], ref), f"case {k} n={n}"
+        assert np.array_equal(isa[sa], np.arange(n + 1))
+        # lcp against a direct computation on a sample of ranks
+        rng = np.random.default_rng(k)
+        for r in rng.integers(1, n + 1, min(n, 200)) if n else []:
+            a, c = int(sa[r - 1]), int(sa[r])
+            l = 0
+            while l < 256 and a + l < n and c + l < n and d[a + l] == d[c + l]:
+                l += 1
+            assert lcp[r] == l
+
+
+def unpack(amd_ty, amd_addr, amd_len):
+    return list(zip(amd_ty.tolist(), amd_addr.tolist(), amd_len.tolist()))
+
+
+@pytest.mark.parametrize("dict_name", ["nil", "dict_naive"])
+def test_best_backrefs_match_oracle(amd, dict_name, dict_naive):
+    """every position's (type, address, length) equals the oracle's bestBackref (compress.go:146-173)"""
+    dict_ = b"" if dict_name == "nil" else dict_naive
+    gc = amd.Compressor(dict_)
+    oc = O.Compressor(dict_)
+    cases = rand_cases() + [fixture_bytes("3c2943_data.bin"), fixture_bytes("average_block.bin")[:30000]]
+    for k, d in enumerate(cases):
+        for start in sorted({0, len(d) // 3}):
+            g = unpack(*gc.best_backrefs(d, start))
+            o = unpack(*oc.best_backrefs(d, start))
+            if g != o:
+                bad = [i for i in range(len(o)) if g[i] != o[i]]
+                raise AssertionError(f"case {k} n={len(d)} start={start}: {len(bad)} differ, first at {start + bad[0]}: "
+                                     f"gpu={g[bad[0]]} oracle={o[bad[0]]}")
+
+
+def test_known_answers(amd):
+    c = amd.Compressor(b"")
+    for d, expect in [(b"", "000100"), (b"hi", "0001006869"), (bytes(8), "00010000fe060000"),
+                      (b"hihihi", "0001006869fe030004"), (bytes([0xFD, 0xFE, 0xFF]), "000100fdff01000010")]:
+        assert c.Compress(d).hex() == expect
+
+
+@pytest.mark.parametrize("dict_name", ["nil", "dict_naive"])
+def test_compress_bytes_match_oracle(amd, dict_name, dict_naive):
+    dict_ = b"" if dict_name == "nil" else dict_naive
+    gc = amd.Compressor(dict_)
+    oc = O.Compressor(dict_)
+    for k, d in enumerate(rand_cases()):
+        assert gc.Compress(d) == oc.compress(d), f"case {k} n={len(d)}"
+        assert gc.CompressedSize256k(d) == oc.compressed_size_256k(d)
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: c["name"] + "/" + c["dict"])
+def test_golden_fixtures(amd, case, dict_naive, average_block):
+    """one-shot Compress of every reference fixture equals the committed golden (oracle) stream"""
+    name = case["name"]
+    d = {"average_block[:102400]": average_block[:102400], "average_block": average_block, "zeros102400": bytes(102400),
+         "zeros300": bytes(300), "hi+zeros300": b"hi" + bytes(300)}.get(name)
+    if d is None:
+        d = fixture_bytes(name)
+    dict_ = b"" if case["dict"] == "nil" else dict_naive
+    out = amd.Compressor(dict_).Compress(d)
+    assert len(out) == case["out_len"]
+    assert hashlib.sha256(out).hexdigest() == case["out_sha256"]
+
+
+def test_batch_synthetic_blobs(amd):
+    """config 2/3 shape: 128 KiB synthetic blobs with the shared 64 KiB dictionary, batched"""
+    dict_ = amd.synth.dictionary()
+    blobs = amd.synth.blobs(0, 6) + [b"", amd.synth.blob(7)[:1000], amd.synth.blob(8)[:77777]]
+    ctx = amd.batch.new_ctx(dict_)
+    got = amd.compress_batch(ctx, blobs)
+    oc = O.Compressor(dict_)
+    for k, d in enumerate(blobs):
+        assert got[k] == oc.compress(d), f"blob {k}"
+    st = oc.phrase_stats()
+    assert st["short"] > 0
+
+
+def test_streaming_matches_oracle(amd, dict_naive, average_block):
+    """Write / Len / Revert / ConsiderBypassing / Reset byte-for-byte (compress_test.go:317-363 flow)"""
+    data = average_block[:40000]
+    gc, oc = amd.Compressor(dict_naive), O.Compressor(dict_naive)
+    in_chunk, out_max = 1000, 5000
+    i0 = 0
+    while i0 < len(data):
+        i = i0
+        while i < len(data) and gc.Len() < out_max:
+            chunk = data[i:min(i + in_chunk, len(data))]
+            gc.Write(chunk)
+            oc.write(chunk)
+            assert gc.Bytes() == oc.bytes()
+            unc = i + in_chunk - i0 + 3
+            if gc.Len() >= out_max and unc <= out_max and gc.Len() > unc:
+                assert gc.ConsiderBypassing() and oc.consider_bypassing()
+            i += in_chunk
+        if gc.Len() > out_max:
+            gc.Revert()
+            oc.revert()
+            i -= in_chunk
+        assert gc.Bytes() == oc.bytes()
+        assert O.decompress(gc.Bytes(), dict_naive) == data[i0:min(i, len(data))]
+        gc.Reset()
+        oc.reset()
+        i0 = i
+
+
+def test_fuzz_like_sequences(amd):
+    rng = np.random.default_rng(3)
+    alphabets = [bytes([0, 1]), bytes([0, 0xFE, 0xFF, 7]), bytes(range(256)), bytes([0xFE, 0xFF])]
+    for t in range(8):
+        alpha = alphabets[t % len(alphabets)]
+        n = int(rng.integers(1, 60))
+        inp = bytes(alpha[j] for j in rng.integers(0, len(alpha), n))
+        dict_ = bytes(alpha[j] for j in rng.integers(0, len(alpha), int(rng.integers(0, 40))))
+        gc, oc = amd.Compressor(dict_), O.Compressor(dict_)
+        for b in inp:
+            gc.Write(bytes([b])); oc.write(bytes([b]))
+            gc.Revert(); oc.revert()
+            gc.Write(bytes([b])); oc.write(bytes([b]))
+            assert gc.Bytes() == oc.bytes()
+        assert O.decompress(gc.Bytes(), dict_) == inp
+        gc.Reset(); oc.reset()
+        gc.Write(inp[:-1]); oc.write(inp[:-1])
+        gc.Write(inp[-1:]); oc.write(inp[-1:])
+        assert gc.Bytes() == oc.bytes()
+
+
+def test_errors(amd):
+    with pytest.raises(amd.LzssError, match="dict size must be <= 4194304"):
+        amd.Compressor(bytes((1 << 22) - 1))
+    c = amd.Compressor(b"")
+    with pytest.raises(amd.LzssError, match="input size must be <= 4194304"):
+        c.Write(bytes((1 << 22) + 1))
+    with pytest.raises(amd.LzssError, match="input size must be <= 262144"):
+        c.CompressedSize256k(bytes(262145))
+    c.Reset()
+    c.Write(b"abc")
+    c.Revert()
+    with pytest.raises(amd.LzssError, match="cannot revert twice in a row"):
+        c.Revert()
