@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""bench.py - compress MB/s of the MI355X lzss path on BASELINE.json's config 3 workload.
+
+A step = one pass of the hot path (suffix-array index build, per-position back-reference search, phrase
+walk, bit emission) over one batch of synthetic 128 KiB calldata-like blobs that share a 64 KiB
+dictionary.  The 10 000-blob batch of config 3 is sharded blob b -> GPU b mod 8, i.e. 1250 blobs per
+GPU; every rank keeps that per-GPU shard size whatever N is (weak scaling, no collective on the data
+path).  Inputs are resident in HBM before the timed region; outputs stay in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--blobs B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blobs", type=int, default=1250, help="blobs per GPU per step (config 3: 10000 / 8)")
+    ap.add_argument("--blob-size", type=int, default=131072)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import compress_amd
+    from compress_amd import batch as B, synth
+
+    # ---- workload: this rank's shard of config 3
+    dict_ = synth.dictionary()
+    ids = [rank + world * k for k in range(args.blobs)]
+    blobs = [synth.blob(b, args.blob_size) for b in ids]
+    in_bytes = sum(map(len, blobs))
+
+    ctx = B.new_ctx(dict_, device=local_rank)
+    bt = B.Batch(ctx, len(blobs), in_bytes)
+    t0 = time.perf_counter()
+    bt.upload(blobs)                       # host -> HBM, outside the timed region
+    t_up = time.perf_counter() - t0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        bt.compress()
+    stage_sum = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bt.compress()                      # returns after the library's stream has drained
+        for k, v in bt.stage_times().items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out_len, nbits, out_total = bt.sizes()
+    t0 = time.perf_counter()
+    outs = bt.download()
+    t_down = time.perf_counter() - t0
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = in_bytes * world * args.steps / elapsed / 1e6
+        stages = {k: v / args.steps for k, v in stage_sum.items() if v > 0}
+        dom = max(stages, key=stages.get)
+        # algorithmic bytes of one launch: sum(n_in + n_out) + n_dict
+        alg_bytes = in_bytes + int(out_total) + len(compress_amd.AugmentDict(dict_))
+        achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
+        line = {
+            "metric": "compress MB/s (whole node, bit-exact) + % HBM roofline at 1/2/4/8 GPUs",
+            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "config3: batch of independent 128 KiB calldata-like blobs, shared 64 KiB dictionary, "
+                                   "blob b -> GPU b mod N", "blobs_per_gpu": len(blobs), "blob_bytes": args.blob_size,
+                       "dict_bytes": len(dict_), "ratio": round(in_bytes / max(1, int(out_total)), 3)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stages[dom], 3)},
+            "stages_ms": {k: round(v, 3) for k, v in stages.items()},
+            "pcie_inclusive_MBps": round(in_bytes / (t_up + elapsed / args.steps + t_down) / 1e6, 2),
+        }
+        # ---- bit-exactness spot check + CPU baseline (oracle = checker / reported baseline only)
+        if not args.no_cpu and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            oc = O.Compressor(dict_)
+            done = 0
+            t0 = time.perf_counter()
+            exact = True
+            while done < len(blobs) and time.perf_counter() - t0 < args.cpu_seconds:
+                ref = oc.compress(blobs[done])
+                exact = exact and (ref == outs[done])
+                done += 1
+            cpu_t = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": round(done * args.blob_size / cpu_t / 1e6, 3), "unit": "MB/s", "cores": 1,
+                                    "kind": "port", "sample": f"first {done} blobs of the same batch, one-shot Compress, "
+                                                              "C restatement of the reference algorithm, 1 thread"}
+            line["bit_exact_vs_oracle"] = {"blobs_checked": done, "all_equal": exact}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

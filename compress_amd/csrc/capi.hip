@@ -99,6 +99,7 @@ struct mi355_lzss_batch {
     uint64_t cap_elems = 0;  // element capacity of the per-position arrays
     // per-position arrays
     DevBuf text, keyA, valA, keyB, valB, rkA, rkB, flags, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
+    DevBuf pmin1, pmax1, pmin2, pmax2, samin1, samin2;  // per 64 entries
     DevBuf entry, tilebit, headb, tailb;  // per 256-tile
     DevBuf segs, nbits, out_off, out_len, status;  // per blob
     DevBuf out;                                    // compressed bytes, blob b at out_off[b]
@@ -138,6 +139,8 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
         const uint64_t e64 = e / 64 + 1, e256 = e / 256 + 1;
         if ((rc = b->b1.ensure(e64 * 2)) != 0) return rc;
         if ((rc = b->b2.ensure(e64 * 2)) != 0) return rc;
+        for (DevBuf *d : {&b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2})
+            if ((rc = d->ensure(e64 * 4)) != 0) return rc;
         if ((rc = b->entry.ensure(e256 * 2)) != 0) return rc;
         if ((rc = b->tilebit.ensure(e256 * 8)) != 0) return rc;
         if ((rc = b->headb.ensure(e256)) != 0) return rc;
@@ -170,6 +173,10 @@ static BatchIndex batch_index(mi355_lzss_batch *b) {
     ix.text = b->text.as<uint8_t>();
     ix.sa = b->sa.as<int32_t>(); ix.isa = b->isa.as<int32_t>();
     ix.lcp = b->lcp.as<uint16_t>(); ix.bmin1 = b->b1.as<uint16_t>(); ix.bmin2 = b->b2.as<uint16_t>();
+    ix.ks = b->keyA.as<int32_t>(); ix.ps = b->valA.as<int32_t>();  // the sort buffers are free once sa_build is done
+    ix.pmin1 = b->pmin1.as<int32_t>(); ix.pmax1 = b->pmax1.as<int32_t>();
+    ix.pmin2 = b->pmin2.as<int32_t>(); ix.pmax2 = b->pmax2.as<int32_t>();
+    ix.samin1 = b->samin1.as<int32_t>(); ix.samin2 = b->samin2.as<int32_t>();
     return ix;
 }
 static WalkWork walk_work(mi355_lzss_batch *b) {
@@ -211,7 +218,7 @@ extern "C" void mi355_lzss_batch_destroy(mi355_lzss_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     DevBuf *bufs[] = {&b->text, &b->keyA, &b->valA, &b->keyB, &b->valB, &b->rkA, &b->rkB, &b->flags, &b->sa, &b->isa,
-                      &b->lcp, &b->b1, &b->b2, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
+                      &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
                       &b->headb, &b->tailb, &b->segs, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->out,
                       &b->d_cin, &b->d_cin_off, &b->d_dout, &b->d_dout_off, &b->d_dlen, &b->d_dstatus};
     for (DevBuf *d : bufs) d->release();
@@ -263,7 +270,7 @@ extern "C" int mi355_lzss_batch_upload(mi355_lzss_batch *b, const uint8_t *in, c
 }
 
 // index build + match search for the uploaded blobs
-static int run_index_and_match(mi355_lzss_batch *b) {
+static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
     hipStream_t sm = b->ctx->stream;
     int rc;
     const Seg *d_segs = b->segs.as<Seg>();
@@ -271,8 +278,9 @@ static int run_index_and_match(mi355_lzss_batch *b) {
     launch_sa_build(d_segs, b->n_blobs, b->text.as<uint8_t>(), sa_work(b), sm);
     if ((rc = mark(b, ST_LCP)) != 0) return rc;
     launch_lcp(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
+    launch_window_index(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
     if ((rc = mark(b, ST_MATCH)) != 0) return rc;
-    launch_match(d_segs, b->n_blobs, b->max_n, batch_index(b), b->ctx->view, b->res.as<uint32_t>(), sm);
+    launch_match(d_segs, b->n_blobs, b->max_n, batch_index(b), b->ctx->view, b->res.as<uint32_t>(), skip_unqueried, sm);
     if ((rc = mark(b, ST_DECIDE)) != 0) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -332,7 +340,7 @@ extern "C" int mi355_lzss_batch_compress(mi355_lzss_batch *b, int with_header) {
     if (!b) return fail(MI355_LZSS_E_ARG, "null argument");
     int rc;
     if ((rc = set_device(b->ctx)) != 0) return rc;
-    if ((rc = run_index_and_match(b)) != 0) return rc;
+    if ((rc = run_index_and_match(b, true)) != 0) return rc;
     if ((rc = run_walk_emit(b, with_header ? LZSS_HEADER_SIZE : 0, 0, true)) != 0) return rc;
     return collect_stage_times(b, ST_SA, ST_EMIT + 1);
 }
@@ -523,7 +531,7 @@ extern "C" int mi355_lzss_best_backrefs(mi355_lzss_ctx *ctx, const uint8_t *d, s
     int rc;
     if ((rc = upload_one(ctx, d, n, start)) != 0) return rc;
     mi355_lzss_batch *b = ctx->scratch;
-    if ((rc = run_index_and_match(b)) != 0) return rc;
+    if ((rc = run_index_and_match(b, false)) != 0) return rc;
     std::vector<uint32_t> packed(n ? n : 1);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if ((rc = mi355_lzss_batch_results(b, 0, packed.data(), n)) != 0) return rc;
@@ -555,7 +563,7 @@ extern "C" int mi355_lzss_write(mi355_lzss_ctx *ctx, const uint8_t *inbuf, size_
     int rc;
     if ((rc = upload_one(ctx, inbuf, n, start)) != 0) return rc;
     mi355_lzss_batch *b = ctx->scratch;
-    if ((rc = run_index_and_match(b)) != 0) return rc;
+    if ((rc = run_index_and_match(b, true)) != 0) return rc;
     if ((rc = run_walk_emit(b, 0, bit_off, true)) != 0) return rc;
     if (nbits) *nbits = b->h_nbits[0];
     const size_t need = b->h_out_len[0];
@@ -570,7 +578,7 @@ extern "C" int mi355_lzss_compressed_size(mi355_lzss_ctx *ctx, const uint8_t *d,
     int rc;
     if ((rc = upload_one(ctx, d, n, 0)) != 0) return rc;
     mi355_lzss_batch *b = ctx->scratch;
-    if ((rc = run_index_and_match(b)) != 0) return rc;
+    if ((rc = run_index_and_match(b, true)) != 0) return rc;
     if ((rc = run_walk_emit(b, LZSS_HEADER_SIZE, 0, false)) != 0) return rc;
     if (size) *size = b->h_out_len[0];
     return 0;

@@ -26,10 +26,20 @@ struct BatchIndex {   // batch-wide index arrays
     uint16_t *lcp;    // [seg.off + k]
     uint16_t *bmin1;  // [seg.off/64 + k/64]
     uint16_t *bmin2;  // [seg.off/64 + k/4096]
+    // window index (sa_build.hip: window_index_kernel): the ranks 1..n regrouped by the 16 KiB chunk of
+    // their position, rank order kept inside a chunk.  Entry j of chunk c sits at [seg.off + c*16384 + j].
+    int32_t *ks;      // rank of the entry
+    int32_t *ps;      // position of the entry (== sa[ks])
+    int32_t *pmin1, *pmax1;  // min / max of ps over blocks of 64 entries   [seg.off/64 + j/64]
+    int32_t *pmin2, *pmax2;  // ... over blocks of 4096 entries             [seg.off/64 + j/4096]
+    int32_t *samin1, *samin2;  // min of sa over blocks of 64 / 4096 ranks  [seg.off/64 + k/64], [.. + k/4096]
 };
+void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream);
 void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream);
+// skip_unqueried: leave out positions the walk provably never asks about (deep inside a run of >= 160
+// equal bytes, compress.go:180-218); their result is then RES_NONE
 void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
-                  uint32_t *d_res, hipStream_t stream);
+                  uint32_t *d_res, bool skip_unqueried, hipStream_t stream);
 
 // ---- emit.hip ---------------------------------------------------------------------------------
 struct WalkWork {

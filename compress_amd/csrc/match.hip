@@ -140,19 +140,113 @@ __device__ inline uint32_t select_backref(const DictView &D, const uint8_t *T, i
     return res_pack(RES_NONE, 0, 0);
 }
 
-// first in-window entry of the rank interval of suffixes sharing >= L bytes with rank kdn, scanning
-// upward from the interval's first rank; kdn itself is in the window, so the scan ends there at the latest
-__device__ inline int leftmost_in_window(const int32_t *SA, const uint16_t *LCP, const uint16_t *b1, const uint16_t *b2,
-                                         int kdn, int L, int ws, int i) {
-    int k = prev_lower(LCP, b1, b2, kdn, L);
-    for (; k < kdn; ++k) {
-        const int p = SA[k];
-        if (p >= ws && p < i) return p;
+// first j in [j0, end) with P[j] < x (LESS) or P[j] >= x (!LESS); `end` if there is none.  m1 / m2 hold the
+// min (LESS) or max (!LESS) of P over blocks of 64 and 4096 entries, so whole blocks without a hit are
+// skipped: at most ~64 steps per level whatever the distance.
+template <bool LESS>
+__device__ inline int next_thr(const int32_t *P, const int32_t *m1, const int32_t *m2, int j0, int end, int x) {
+    int j = j0;
+    while (j < end) {
+        const int v = P[j];
+        if (LESS ? v < x : v >= x) return j;
+        ++j;
+        if ((j & 63) == 0) break;
     }
-    return SA[kdn];
+    if (j >= end) return end;
+    int b = j >> 6;
+    const int bend = (end + 63) >> 6;
+    while (b < bend) {
+        if ((b & 63) == 0) {
+            const int v2 = m2[b >> 6];
+            if (LESS ? v2 >= x : v2 < x) { b += 64; continue; }
+        }
+        const int v1 = m1[b];
+        if (LESS ? v1 < x : v1 >= x) break;
+        ++b;
+    }
+    if (b >= bend) return end;
+    for (j = b << 6; j < end; ++j) {
+        const int v = P[j];
+        if (LESS ? v < x : v >= x) return j;
+    }
+    return end;
 }
 
-__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, BatchIndex ix, DictView D, uint32_t *res) {
+struct SegIndex {  // one segment's view of BatchIndex
+    const int32_t *SA;
+    const uint16_t *LCP, *b1, *b2;
+    const int32_t *KS, *PS, *pmin1, *pmax1, *pmin2, *pmax2, *samin1, *samin2;
+    int n;
+};
+
+constexpr int LINEAR_SPAN = 24;  // intervals up to this many ranks are scanned directly
+
+// Smallest-rank occurrence inside the SHORT window [ws, i) among the suffixes sharing >= L bytes with
+// rank kdn (which is itself in the window, so the answer is <= kdn).
+__device__ inline int leftmost_short(const SegIndex &S, int kdn, int L, int ws, int i) {
+    const int lo = prev_lower(S.LCP, S.b1, S.b2, kdn, L);
+    if (kdn - lo <= LINEAR_SPAN) {
+        for (int k = lo; k < kdn; ++k) {
+            const int p = S.SA[k];
+            if (p >= ws && p < i) return p;
+        }
+        return S.SA[kdn];
+    }
+    int best = kdn;
+    const int c2 = (i - 1) >> LZSS_SHORT_ADDR_BITS;  // chunk of the window's last position: entries with pos < i
+    {
+        const int beg = c2 << LZSS_SHORT_ADDR_BITS;
+        const int end = (beg + LZSS_SHORT_WINDOW) < S.n ? (beg + LZSS_SHORT_WINDOW) : S.n;
+        int a = beg, b = end;
+        while (a < b) {  // first entry of the chunk with rank >= lo
+            const int h = (a + b) >> 1;
+            if (S.KS[h] < lo) a = h + 1; else b = h;
+        }
+        const int j = next_thr<true>(S.PS, S.pmin1, S.pmin2, a, end, i);
+        if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
+    }
+    if (c2 >= 1 && ws < (c2 << LZSS_SHORT_ADDR_BITS)) {  // previous chunk: entries with pos >= ws
+        const int beg = (c2 - 1) << LZSS_SHORT_ADDR_BITS;
+        const int end = beg + LZSS_SHORT_WINDOW;
+        int a = beg, b = end;
+        while (a < b) {
+            const int h = (a + b) >> 1;
+            if (S.KS[h] < lo) a = h + 1; else b = h;
+        }
+        const int j = next_thr<false>(S.PS, S.pmax1, S.pmax2, a, end, ws);
+        if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
+    }
+    return S.SA[best];
+}
+
+// the same for the LONG window [ws, i); ws == 0 whenever i <= 2^21, and then "pos < i" over the suffix
+// array itself is a one-sided condition
+__device__ inline int leftmost_long(const SegIndex &S, int kdn, int L, int ws, int i) {
+    const int lo = prev_lower(S.LCP, S.b1, S.b2, kdn, L);
+    if (ws == 0 && kdn - lo > LINEAR_SPAN) {
+        const int k = next_thr<true>(S.SA, S.samin1, S.samin2, lo, kdn + 1, i);
+        return S.SA[k <= kdn ? k : kdn];
+    }
+    for (int k = lo; k < kdn; ++k) {
+        const int p = S.SA[k];
+        if (p >= ws && p < i) return p;
+    }
+    return S.SA[kdn];
+}
+
+// true when the walk can never call bestBackref(i): i, i-1 and i-2 lie in one run of equal bytes and at
+// least 160 of them follow i, so the RLE branch (compress.go:184) is taken at i, i-1 and i-2
+__device__ inline bool never_queried(const uint8_t *T, int n, int i) {
+    if (i < 2 || n - i < LZSS_MIN_REPEAT) return false;
+    const uint8_t c = T[i];
+    if (T[i - 1] != c || T[i - 2] != c) return false;
+    const uint64_t pat = 0x0101010101010101ull * c;
+    for (int o = 0; o < LZSS_MIN_REPEAT; o += 8)
+        if (ld8(T + i + o) != pat) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, BatchIndex ix, DictView D, uint32_t *res, int skip_unqueried) {
     const Seg sg = segs[blockIdx.y];
     const int n = (int)sg.n;
     const int N = n + 1;
@@ -167,6 +261,17 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
 
     const int i = SA[r];
     if (i < (int)sg.start || i < HEAD) return;
+    if (skip_unqueried && never_queried(T, n, i)) {
+        res[sg.off + i] = res_pack(RES_NONE, 0, 0);
+        return;
+    }
+    SegIndex S;
+    S.SA = SA; S.LCP = LCP; S.b1 = b1; S.b2 = b2;
+    S.KS = ix.ks + sg.off; S.PS = ix.ps + sg.off;
+    S.pmin1 = ix.pmin1 + sg.off / 64; S.pmax1 = ix.pmax1 + sg.off / 64;
+    S.pmin2 = ix.pmin2 + sg.off / 64; S.pmax2 = ix.pmax2 + sg.off / 64;
+    S.samin1 = ix.samin1 + sg.off / 64; S.samin2 = ix.samin2 + sg.off / 64;
+    S.n = n;
 
     const int maxLen = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
     const bool reserved = T[i] >= LZSS_SYMBOL_SHORT;
@@ -211,14 +316,14 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
     {
         const int ld = LdnS >= minS ? LdnS : 0, lu = LupS >= minS ? LupS : 0;
         Ls = ld > lu ? ld : lu;
-        if (Ls > 0) ps = (lu > ld) ? pupS : leftmost_in_window(SA, LCP, b1, b2, kdnS, Ls, wsS, i);
+        if (Ls > 0) ps = (lu > ld) ? pupS : leftmost_short(S, kdnS, Ls, wsS, i);
     }
     // long window
     int LL = 0, pL = -1;
     if (dynOK) {
         const int ld = LdnL >= minD ? LdnL : 0, lu = LupL >= minD ? LupL : 0;
         LL = ld > lu ? ld : lu;
-        if (LL > 0) pL = (lu > ld) ? pupL : leftmost_in_window(SA, LCP, b1, b2, kdnL, LL, wsL, i);
+        if (LL > 0) pL = (lu > ld) ? pupL : leftmost_long(S, kdnL, LL, wsL, i);
     }
     res[sg.off + i] = select_backref(D, T, i, maxLen, minD, dynOK, Ls, ps, LL, pL);
 }
@@ -253,14 +358,14 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
 }
 
 void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
-                  uint32_t *d_res, hipStream_t stream) {
+                  uint32_t *d_res, bool skip_unqueried, hipStream_t stream) {
     if (n_segs == 0 || max_n == 0) return;
     const uint32_t head = max_n < (uint32_t)HEAD ? max_n : (uint32_t)HEAD;
     dim3 gh((head + 63) / 64, n_segs);
     hipLaunchKernelGGL(match_head_kernel, gh, dim3(64), 0, stream, d_segs, ix, dict, d_res);
     if (max_n > (uint32_t)HEAD) {
         dim3 g((max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS, n_segs);
-        hipLaunchKernelGGL(match_kernel, g, dim3(MATCH_THREADS), 0, stream, d_segs, ix, dict, d_res);
+        hipLaunchKernelGGL(match_kernel, g, dim3(MATCH_THREADS), 0, stream, d_segs, ix, dict, d_res, skip_unqueried ? 1 : 0);
     }
 }
 

@@ -308,6 +308,101 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
     }
 }
 
+// ---- window index: ranks regrouped by the 16 KiB chunk of their position (stable in rank order) ------
+// Lets the match kernel answer "first rank >= lo whose position lies in [i - 2^14, i)" without walking
+// the suffix array: the window meets at most two chunks, and inside a chunk the condition is one-sided.
+constexpr int WIN_SHIFT = LZSS_SHORT_ADDR_BITS;  // chunk = 2^14 positions
+
+__global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *segs, BatchIndex ix) {
+    __shared__ SaShared sh;
+    const Seg sg = segs[blockIdx.x];
+    const uint32_t n = sg.n;
+    if (n == 0) return;
+    const uint32_t N = n + 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int32_t *SA = ix.sa + sg.off;
+    int32_t *KS = ix.ks + sg.off, *PS = ix.ps + sg.off;
+    const int nch = (int)((n + (1u << WIN_SHIFT) - 1) >> WIN_SHIFT);  // <= 256 for n <= 4 MiB
+
+    // ranks 1..n (rank 0 is the sentinel), one chunk of the rank range per wave
+    const uint32_t C = (((n + SA_WAVES - 1) / SA_WAVES) + 63u) & ~63u;
+    const uint32_t cbeg = 1 + min((uint32_t)w * C, n), cend = min(cbeg + C, N);
+
+    hist_clear(sh, tid);
+    __syncthreads();
+    for (uint32_t k0 = cbeg; k0 < cend; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const bool active = k < cend;
+        const int c = active ? (SA[k] >> WIN_SHIFT) : 0;
+        hist_add(sh.hist[w], c, active, lane);
+    }
+    __syncthreads();
+    if (tid < nch) {  // first slot of wave w inside chunk tid
+        int s = tid << WIN_SHIFT;
+        for (int ww = 0; ww < SA_WAVES; ++ww) {
+            const int t = sh.hist[ww][tid];
+            sh.hist[ww][tid] = s;
+            s += t;
+        }
+    }
+    __syncthreads();
+    int32_t *hrow = sh.hist[w];
+    for (uint32_t k0 = cbeg; k0 < cend; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const bool active = k < cend;
+        const int p = active ? SA[k] : 0;
+        const int c = p >> WIN_SHIFT;
+        const uint64_t amask = __ballot(active);
+        const uint64_t peers = match_digit(c, amask);
+        const int cnt = __popcll(peers);
+        const int rank = __popcll(peers & lanemask_lt(lane));
+        const int base = hrow[c];
+        if (active) {
+            KS[base + rank] = (int)k;
+            PS[base + rank] = p;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (active && rank == cnt - 1) hrow[c] = base + cnt;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// min / max over blocks of 64 entries of a per-segment int32 array with `count(seg)` entries
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void block64_kernel(const Seg *segs, const int32_t *in, int32_t *out, int level, int extra) {
+    const Seg sg = segs[blockIdx.y];
+    // level 0: entries of the array itself ([off + j], count n + extra); level 1: the level-0 summaries
+    uint32_t count = sg.n + (uint32_t)extra;
+    const int32_t *src = in + sg.off;
+    if (level == 1) {
+        count = (count + 63) / 64;
+        src = in + sg.off / 64;
+    }
+    if (blockIdx.x * 256 >= count) return;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    int v = IS_MAX ? INT_MIN : INT_MAX;
+    if (j < count) v = src[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int t = __shfl_xor(v, o);
+        v = IS_MAX ? (t > v ? t : v) : (t < v ? t : v);
+    }
+    if ((threadIdx.x & 63) == 0) out[sg.off / 64 + (j >> 6)] = v;
+}
+
+void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream) {
+    if (n_segs == 0 || max_n == 0) return;
+    hipLaunchKernelGGL(window_index_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, ix);
+    const uint32_t c0 = max_n + 1, c1 = (c0 + 63) / 64;
+    dim3 g0((c0 + 255) / 256, n_segs), g1((c1 + 255) / 256, n_segs);
+    hipLaunchKernelGGL(block64_kernel<false>, g0, dim3(256), 0, stream, d_segs, ix.ps, ix.pmin1, 0, 0);
+    hipLaunchKernelGGL(block64_kernel<true>, g0, dim3(256), 0, stream, d_segs, ix.ps, ix.pmax1, 0, 0);
+    hipLaunchKernelGGL(block64_kernel<false>, g0, dim3(256), 0, stream, d_segs, ix.sa, ix.samin1, 0, 1);
+    hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.pmin1, ix.pmin2, 1, 0);
+    hipLaunchKernelGGL(block64_kernel<true>, g1, dim3(256), 0, stream, d_segs, ix.pmax1, ix.pmax2, 1, 0);
+    hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.samin1, ix.samin2, 1, 1);
+}
+
 void launch_sa_build(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const SaWork &wk, hipStream_t stream) {
     if (n_segs == 0) return;
     hipLaunchKernelGGL(sa_build_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, d_text, wk);
