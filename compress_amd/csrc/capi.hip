@@ -598,17 +598,92 @@ extern "C" int mi355_lzss_compress_batch(mi355_lzss_ctx *ctx, const uint8_t *in,
 }
 
 // ---- decompression: see decompress.hip ----------------------------------------------------------------------
-extern "C" int mi355_lzss_decompress_batch(mi355_lzss_ctx *, const uint8_t *, const uint64_t *, uint32_t, uint8_t *,
-                                           const uint64_t *, uint32_t *, int32_t *) {
-    return fail(MI355_LZSS_E_DEVICE, "decompress_batch: not built yet");
+extern "C" int mi355_lzss_batch_upload_compressed(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *in_off,
+                                                  uint32_t n_blobs, const uint64_t *out_cap_off) {
+    if (!b || !in_off || !out_cap_off || (n_blobs && !in)) return fail(MI355_LZSS_E_ARG, "null argument");
+    int rc;
+    if ((rc = set_device(b->ctx)) != 0) return rc;
+    for (uint32_t k = 0; k < n_blobs; ++k)
+        if (in_off[k + 1] < in_off[k] || out_cap_off[k + 1] < out_cap_off[k])
+            return fail(MI355_LZSS_E_ARG, "offsets must be non-decreasing");
+    // rebase both offset arrays to 0
+    b->h_cin_off.assign(n_blobs + 1, 0);
+    b->h_dout_off.assign(n_blobs + 1, 0);
+    for (uint32_t k = 0; k <= n_blobs; ++k) {
+        b->h_cin_off[k] = in_off[k] - in_off[0];
+        b->h_dout_off[k] = out_cap_off[k] - out_cap_off[0];
+    }
+    const uint64_t cin = b->h_cin_off[n_blobs], dout = b->h_dout_off[n_blobs];
+    if ((rc = b->d_cin.ensure((size_t)cin + 16)) != 0) return rc;
+    if ((rc = b->d_dout.ensure((size_t)std::max<uint64_t>(dout, 16))) != 0) return rc;
+    if ((rc = b->d_cin_off.ensure((n_blobs + 1) * 8)) != 0) return rc;
+    if ((rc = b->d_dout_off.ensure((n_blobs + 1) * 8)) != 0) return rc;
+    if ((rc = b->d_dlen.ensure(std::max<uint32_t>(n_blobs, 1) * 4)) != 0) return rc;
+    if ((rc = b->d_dstatus.ensure(std::max<uint32_t>(n_blobs, 1) * 4)) != 0) return rc;
+    hipStream_t sm = b->ctx->stream;
+    HIP_TRY(hipMemsetAsync((uint8_t *)b->d_cin.p + cin, 0, 16, sm));
+    if (cin) HIP_TRY(hipMemcpyAsync(b->d_cin.p, in + in_off[0], (size_t)cin, hipMemcpyHostToDevice, sm));
+    HIP_TRY(hipMemcpyAsync(b->d_cin_off.p, b->h_cin_off.data(), (n_blobs + 1) * 8, hipMemcpyHostToDevice, sm));
+    HIP_TRY(hipMemcpyAsync(b->d_dout_off.p, b->h_dout_off.data(), (n_blobs + 1) * 8, hipMemcpyHostToDevice, sm));
+    HIP_TRY(hipStreamSynchronize(sm));
+    b->n_dblobs = n_blobs;
+    return 0;
 }
-extern "C" int mi355_lzss_batch_upload_compressed(mi355_lzss_batch *, const uint8_t *, const uint64_t *, uint32_t,
-                                                  const uint64_t *) {
-    return fail(MI355_LZSS_E_DEVICE, "decompress_batch: not built yet");
+
+extern "C" int mi355_lzss_batch_decompress(mi355_lzss_batch *b) {
+    if (!b) return fail(MI355_LZSS_E_ARG, "null argument");
+    int rc;
+    mi355_lzss_ctx *ctx = b->ctx;
+    if ((rc = set_device(ctx)) != 0) return rc;
+    if ((rc = mark(b, ST_DECOMP)) != 0) return rc;
+    launch_decompress(b->d_cin.as<uint8_t>(), b->d_cin_off.as<uint64_t>(), b->n_dblobs, b->d_dout.as<uint8_t>(),
+                      b->d_dout_off.as<uint64_t>(), ctx->view.T, ctx->view.n, b->d_dlen.as<uint32_t>(),
+                      b->d_dstatus.as<int32_t>(), ctx->stream);
+    if ((rc = mark(b, ST_DECOMP + 1)) != 0) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    return collect_stage_times(b, ST_DECOMP, ST_DECOMP + 1);
 }
-extern "C" int mi355_lzss_batch_decompress(mi355_lzss_batch *) {
-    return fail(MI355_LZSS_E_DEVICE, "decompress_batch: not built yet");
+
+extern "C" int mi355_lzss_batch_download_decompressed(mi355_lzss_batch *b, uint8_t *out, const uint64_t *out_off,
+                                                      uint32_t *out_len, int32_t *status) {
+    if (!b || !out_off || (b->n_dblobs && !out)) return fail(MI355_LZSS_E_ARG, "null argument");
+    int rc;
+    if ((rc = set_device(b->ctx)) != 0) return rc;
+    const uint32_t nb = b->n_dblobs;
+    if (nb == 0) return 0;
+    std::vector<uint32_t> lens(nb);
+    std::vector<int32_t> sts(nb);
+    hipStream_t sm = b->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(lens.data(), b->d_dlen.p, nb * 4, hipMemcpyDeviceToHost, sm));
+    HIP_TRY(hipMemcpyAsync(sts.data(), b->d_dstatus.p, nb * 4, hipMemcpyDeviceToHost, sm));
+    HIP_TRY(hipStreamSynchronize(sm));
+    const uint64_t total = b->h_dout_off[nb];
+    if (total) {
+        if ((rc = b->h_stage.ensure((size_t)total)) != 0) return rc;
+        HIP_TRY(hipMemcpyAsync(b->h_stage.p, b->d_dout.p, (size_t)total, hipMemcpyDeviceToHost, sm));
+        HIP_TRY(hipStreamSynchronize(sm));
+    }
+    int worst = 0;
+    for (uint32_t k = 0; k < nb; ++k) {
+        int32_t st = sts[k];
+        const uint64_t cap = out_off[k + 1] - out_off[k];
+        if (st == 0 && lens[k] > cap) st = MI355_LZSS_E_CAPACITY;
+        if (st == 0 && lens[k]) memcpy(out + out_off[k], b->h_stage.as<uint8_t>() + b->h_dout_off[k], lens[k]);
+        if (out_len) out_len[k] = st == 0 ? lens[k] : 0;
+        if (status) status[k] = st;
+        if (st && !worst) worst = st;
+    }
+    if (worst && !status) return fail(worst, "blob failed with status %d", worst);
+    return 0;
 }
-extern "C" int mi355_lzss_batch_download_decompressed(mi355_lzss_batch *, uint8_t *, const uint64_t *, uint32_t *, int32_t *) {
-    return fail(MI355_LZSS_E_DEVICE, "decompress_batch: not built yet");
+
+extern "C" int mi355_lzss_decompress_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
+                                           uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
+    if (!ctx || !in_off || !out_off) return fail(MI355_LZSS_E_ARG, "null argument");
+    int rc;
+    mi355_lzss_batch *b = ctx->scratch;
+    if ((rc = mi355_lzss_batch_upload_compressed(b, in, in_off, n_blobs, out_off)) != 0) return rc;
+    if ((rc = mi355_lzss_batch_decompress(b)) != 0) return rc;
+    return mi355_lzss_batch_download_decompressed(b, out, out_off, out_len, status);
 }

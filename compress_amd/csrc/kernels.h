@@ -64,4 +64,10 @@ void launch_emit(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, cons
                  uint32_t header_bytes, uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                  uint8_t *d_out, uint64_t out_cap, int32_t *d_status, hipStream_t stream);
 
+// ---- decompress.hip ---------------------------------------------------------------------------
+// in / out: CSR offsets (n_blobs + 1 entries, device); the input buffer must be readable 16 bytes past its end
+void launch_decompress(const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n_blobs, uint8_t *d_out,
+                       const uint64_t *d_out_off, const uint8_t *d_dict, uint32_t dict_len, uint32_t *d_out_len,
+                       int32_t *d_status, hipStream_t stream);
+
 }  // namespace lzss

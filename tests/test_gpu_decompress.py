@@ -1,0 +1,111 @@
+"""GPU parity tests (-m gpu) of the batched decompressor against the oracle's Decompress
+(lzss/decompress.go:17-84), through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import fixture_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import compress_amd
+    from compress_amd import batch, synth
+    compress_amd.batch = batch
+    compress_amd.synth = synth
+    return compress_amd
+
+
+def test_known_streams(amd):
+    assert amd.Decompress(bytes.fromhex("00010001fe040000"), b"") == bytes([1] * 6)  # compress_test.go:379-392
+    assert amd.Decompress(bytes.fromhex("000100fdff01000010"), b"") == bytes([0xFD, 0xFE, 0xFF])
+    assert amd.Decompress(bytes.fromhex("00010000fe060000"), b"") == bytes(8)
+    assert amd.Decompress(b"\x00\x01\x00", b"") == b""
+    assert amd.Decompress(b"\x00\x01\x01abc", b"") == b"abc"     # NoCompression, decompress.go:29-31
+
+
+def test_invalid_streams(amd):
+    field = (1 - 255 - 1) & 0x3FFF                                   # compress_test.go:394-404
+    bits = (0xFE << 22) | (4 << 14) | field
+    bad = bytes.fromhex("000100") + (bits << 2).to_bytes(4, "big")
+    with pytest.raises(amd.LzssError):
+        amd.Decompress(bad, b"")
+    with pytest.raises(amd.LzssError, match="unsupported compressor version"):
+        amd.Decompress(b"\x00\x02\x00", b"")
+    with pytest.raises(amd.LzssError, match="expected 0 or 1"):
+        amd.Decompress(b"\x00\x01\x02", b"")
+    with pytest.raises(amd.LzssError):
+        amd.Decompress(b"\x00\x01", b"")
+    with pytest.raises(amd.LzssError):                              # truncated reference -> the reader's EOF
+        amd.Decompress(bytes.fromhex("00010001fe04"), b"")
+    # a long reference that starts in the dictionary but would run past its end (decompress.go:66-69)
+    ctx = amd.batch.new_ctx(b"abcdef")
+    bits = (0xFF << 29) | (4 << 21) | (2 - 1)   # len 5, address 2 with empty output: dict[6:11) of 8
+    res = amd.decompress_batch(ctx, [bytes.fromhex("000100") + (bits << 3).to_bytes(5, "big")], 64)
+    assert isinstance(res[0], amd.LzssError)
+    with pytest.raises(O.OracleError):
+        O.decompress(bytes.fromhex("000100") + (bits << 3).to_bytes(5, "big"), b"abcdef")
+
+
+def test_batch_roundtrip_matches_oracle(amd, dict_naive, average_block):
+    rng = np.random.default_rng(9)
+    inputs = [b"", b"a", bytes(8), bytes(300), b"hi" + bytes(300), bytes([0xFF]) * 500, bytes([0xFE]) * 170 + b"x",
+              b"abc" * 700, average_block[:50000], fixture_bytes("3c2943_data.bin"), fixture_bytes("blobs_1-goerli-3690632")]
+    for k in (2, 3, 256):
+        inputs.append(bytes(rng.integers(0, k, 3000, dtype=np.uint8)))
+    oc = O.Compressor(dict_naive)
+    streams = [bytes(oc.compress(d)) for d in inputs]
+    streams.append(b"\x00\x01\x01" + b"raw bytes")
+    inputs.append(b"raw bytes")
+    ctx = amd.batch.new_ctx(dict_naive)
+    caps = [len(d) + 7 for d in inputs]
+    got = amd.decompress_batch(ctx, streams, caps)
+    for k, d in enumerate(inputs):
+        assert got[k] == d, f"blob {k}"
+        assert O.decompress(streams[k], dict_naive) == d
+    # capacity one byte short -> per-blob status, the others are unaffected
+    caps[8] = len(inputs[8]) - 1
+    got = amd.decompress_batch(ctx, streams, caps)
+    assert isinstance(got[8], amd.LzssError) and got[8].code == -5
+    assert got[9] == inputs[9]
+
+
+def test_gpu_compress_then_gpu_decompress_config5(amd):
+    """config 5 shape: compressed synthetic 128 KiB blobs (overlapping run-length references included)"""
+    dict_ = amd.synth.dictionary()
+    blobs = amd.synth.blobs(100, 12)
+    ctx = amd.batch.new_ctx(dict_)
+    comp = amd.compress_batch(ctx, blobs)
+    oc = O.Compressor(dict_)
+    assert comp[0] == oc.compress(blobs[0])
+    assert oc.phrase_stats()["rle"] > 0
+    b = amd.batch.Batch(ctx, len(blobs), sum(map(len, blobs)))
+    b.upload_compressed(comp, 131072)
+    b.decompress()
+    back = b.download_decompressed()
+    assert back == blobs
+    assert b.stage_times()["decompress"] > 0
+
+
+def test_streaming_blobs_decode_on_gpu(amd, dict_naive, average_block):
+    """blobs produced by the Write/Revert flow (non-zero pad bits after Revert) decode to the exact spans"""
+    data = average_block[:20000]
+    gc = amd.Compressor(dict_naive)
+    spans, streams = [], []
+    i0 = 0
+    while i0 < len(data):
+        i = i0
+        while i < len(data) and gc.Len() < 3000:
+            gc.Write(data[i:i + 500])
+            i += 500
+        if gc.Len() > 3000:
+            gc.Revert()
+            i -= 500
+        spans.append(data[i0:min(i, len(data))])
+        streams.append(gc.Bytes())
+        gc.Reset()
+        i0 = i
+    got = amd.decompress_batch(gc, streams, 20000)
+    assert got == spans
