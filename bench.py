@@ -47,11 +47,11 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import compress_amd
-    from compress_amd import batch as B, synth
+    from compress_amd import batch as B, shard, synth
 
     # ---- workload: this rank's shard of config 3
     dict_ = synth.dictionary()
-    ids = [rank + world * k for k in range(args.blobs)]
+    ids = shard.shard_ids(rank, world, args.blobs)
     blobs = [synth.blob(b, args.blob_size) for b in ids]
     in_bytes = sum(map(len, blobs))
 
@@ -77,15 +77,27 @@ def main():
             stage_sum[k] = stage_sum.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, device="cuda")
 
     out_len, nbits, out_total = bt.sizes()
     t0 = time.perf_counter()
     outs = bt.download()
     t_down = time.perf_counter() - t0
+
+    # ---- secondary kernel (config 5): batched decompression of the streams just produced, HBM resident
+    bt.upload_compressed(outs, args.blob_size)
+    bt.decompress()
+    barrier()
+    t0 = time.perf_counter()
+    dec_ms = 0.0
+    for _ in range(args.steps):
+        bt.decompress()
+        dec_ms += bt.stage_times()["decompress"]
+    barrier()
+    dec_elapsed = time.perf_counter() - t0
+    dec_elapsed = shard.max_over_ranks(dec_elapsed, device="cuda")
+    back = bt.download_decompressed()
+    dec_ok = back == blobs
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -107,6 +119,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stages[dom], 3)},
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
+            "decompress": {"value": round(in_bytes * world * args.steps / dec_elapsed / 1e6, 2), "unit": "MB/s (decompressed bytes)",
+                           "kernel_ms": round(dec_ms / args.steps, 3), "roundtrip_equal": dec_ok,
+                           "achieved_GBps": round((in_bytes + int(out_total)) / (dec_ms / args.steps * 1e-3) / 1e9, 3)},
             "pcie_inclusive_MBps": round(in_bytes / (t_up + elapsed / args.steps + t_down) / 1e6, 2),
         }
         # ---- bit-exactness spot check + CPU baseline (oracle = checker / reported baseline only)
