@@ -275,7 +275,7 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
     int rc;
     const Seg *d_segs = b->segs.as<Seg>();
     if ((rc = mark(b, ST_SA)) != 0) return rc;
-    launch_sa_build(d_segs, b->n_blobs, b->text.as<uint8_t>(), sa_work(b), sm);
+    launch_sa_build(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
     if ((rc = mark(b, ST_LCP)) != 0) return rc;
     launch_lcp(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
     launch_window_index(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
@@ -468,7 +468,7 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     ctx->scratch = b;
     const uint64_t off2[2] = {0, aug.size()};
     if ((rc = mi355_lzss_batch_upload(b, aug.data(), off2, 1, nullptr)) != 0) return bail(rc);
-    launch_sa_build(b->segs.as<Seg>(), 1, b->text.as<uint8_t>(), sa_work(b), ctx->stream);
+    launch_sa_build(b->segs.as<Seg>(), 1, b->max_n, b->text.as<uint8_t>(), sa_work(b), ctx->stream);
     launch_lcp(b->segs.as<Seg>(), 1, b->max_n, batch_index(b), ctx->stream);
     const size_t stride = (size_t)seg_stride(aug.size());
     if ((rc = ctx->d_text.ensure(stride)) != 0) return bail(rc);

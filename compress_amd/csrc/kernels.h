@@ -11,7 +11,8 @@ struct SaWork {       // batch-wide arrays, indexed [seg.off + k], k in [0, n]
     uint8_t *flags;                      // group-boundary flags
     int32_t *sa, *isa;                   // outputs
 };
-void launch_sa_build(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const SaWork &wk, hipStream_t stream);
+void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
+                     hipStream_t stream);
 
 // ---- match.hip --------------------------------------------------------------------------------
 struct DictView {     // the dictionary index of a ctx (device pointers)

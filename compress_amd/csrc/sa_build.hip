@@ -144,7 +144,8 @@ __device__ inline void count_chunk(SaShared &sh, const int32_t *kin, uint32_t cb
     }
 }
 
-__global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk) {
+// Fallback for texts whose activity bitmap does not fit LDS: every round sorts ALL suffixes.
+__global__ __launch_bounds__(SA_THREADS) void sa_build_full_kernel(const Seg *segs, const uint8_t *text, SaWork wk) {
     __shared__ SaShared sh;
     const Seg sg = segs[blockIdx.x];
     const uint8_t *T = text + sg.off;
@@ -308,6 +309,237 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
     }
 }
 
+
+// ---- main kernel: rounds touch only the suffixes that still share their group ----------------------------
+// A bitmap in LDS (one bit per suffix) marks the suffixes whose group has more than one member.  Per round:
+//   A  one coalesced sweep over the current order keeps the marked members of the induction sequence
+//      (p = SA[j] - h) in wave-private compact lists;
+//   B  the lists are concatenated into a dense array with their rank keys (one gather per ACTIVE suffix);
+//   C  the same stable LSD radix passes as the fallback, over the dense array only;
+//   D  boundaries of (old group, second key) give every active suffix its new group start and its slot in
+//      the suffix array (old group start + index inside the group); suffixes now alone leave the bitmap.
+// Suffixes that are alone in their group never move again, so SA and the ranks are updated in place.
+constexpr uint32_t SA_BITMAP_MAX_N = 300000;  // bitmap words live in dynamic LDS
+
+struct SaShared2 {
+    SaShared s;
+    int32_t wbase[SA_WAVES + 1];
+    int32_t wlastS[SA_WAVES];
+};
+
+__global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk) {
+    __shared__ SaShared2 sh2;
+    extern __shared__ uint32_t bits[];
+    SaShared &sh = sh2.s;
+    const Seg sg = segs[blockIdx.x];
+    const uint8_t *T = text + sg.off;
+    const uint32_t n = sg.n;
+    const uint32_t N = n + 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    int32_t *keyA = wk.keyA + sg.off, *valA = wk.valA + sg.off;
+    int32_t *keyB = wk.keyB + sg.off, *valB = wk.valB + sg.off;
+    uint8_t *flags = wk.flags + sg.off;
+    int32_t *sa = wk.sa + sg.off, *rk = wk.isa + sg.off;
+
+    if (N == 1) {
+        if (tid == 0) {
+            sa[0] = 0;
+            rk[0] = 0;
+        }
+        return;
+    }
+    const uint32_t C = (((N + SA_WAVES - 1) / SA_WAVES) + 63u) & ~63u;
+    const uint32_t cbeg = min((uint32_t)w * C, N), cend = min(cbeg + C, N);
+    const int KB = 32 - __clz((int)(N - 1));
+    const int P = (KB + SA_MAXDB - 1) / SA_MAXDB;
+    const int DB = (KB + P - 1) / P;
+    const int mask = (1 << DB) - 1;
+
+    for (uint32_t x = tid; x < (N + 31) / 32; x += SA_THREADS) bits[x] = 0;
+
+    // ---- initial order by first symbol (full pass)
+    hist_clear(sh, tid);
+    __syncthreads();
+    for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool active = j < cend;
+        int key = 0;
+        if (active) {
+            key = j < n ? (int)T[j] + 1 : 0;
+            keyA[j] = key;
+            valA[j] = (int)j;
+        }
+        hist_add(sh.hist[w], key, active, lane);
+    }
+    hist_scan(sh, tid, SA_BINS);
+    scatter_chunk(sh, keyA, valA, keyB, valB, cbeg, cend, 0, SA_BINS - 1, w, lane);
+    __syncthreads();
+
+    const int32_t *kcur = keyB, *vcur = valB;  // sorted (key, suffix) of the current round, dense
+    uint32_t m = N;                            // its length
+    uint32_t dbeg = cbeg, dend = cend;         // this wave's chunk of it
+    uint32_t h = 0;
+    bool initial = true;
+    for (;;) {
+        // ---- D: boundaries, new group starts, slots
+        {
+            int lastK = -1, lastS = -1;
+            int c1 = 0, c2 = 0;
+            for (uint32_t u0 = dbeg; u0 < dend; u0 += 64) {
+                const uint32_t u = u0 + lane;
+                const bool act = u < dend;
+                int p = 0, k1 = -2, k2 = -1;
+                if (act) {
+                    p = vcur[u];
+                    k1 = kcur[u];
+                    if (!initial && (uint32_t)p + h < N) k2 = rk[(uint32_t)p + h];
+                }
+                int q1 = __shfl_up(k1, 1), q2 = __shfl_up(k2, 1);
+                if (lane == 0) {
+                    if (u0 == dbeg) {
+                        if (u > 0) {
+                            const int pp = vcur[u - 1];
+                            q1 = kcur[u - 1];
+                            q2 = (!initial && (uint32_t)pp + h < N) ? rk[(uint32_t)pp + h] : -1;
+                        } else {
+                            q1 = -3;
+                        }
+                    } else {
+                        q1 = c1;
+                        q2 = c2;
+                    }
+                }
+                const bool fK = act && k1 != q1;
+                const bool fS = act && (fK || k2 != q2);
+                c1 = __shfl(k1, 63);
+                c2 = __shfl(k2, 63);
+                if (act) flags[u] = (uint8_t)((fK ? 1 : 0) | (fS ? 2 : 0));
+                const uint64_t bK = __ballot(fK), bS = __ballot(fS);
+                if (bK) lastK = (int)u0 + 63 - __clzll(bK);
+                if (bS) lastS = (int)u0 + 63 - __clzll(bS);
+            }
+            if (lane == 0) {
+                sh.wlast[w] = lastK;
+                sh2.wlastS[w] = lastS;
+            }
+            __syncthreads();
+            int carryK = -1, carryS = -1;
+            for (int ww = 0; ww < w; ++ww) {
+                carryK = max(carryK, sh.wlast[ww]);
+                carryS = max(carryS, sh2.wlastS[ww]);
+            }
+            int rem = 0;
+            for (uint32_t u0 = dbeg; u0 < dend; u0 += 64) {
+                const uint32_t u = u0 + lane;
+                const bool act = u < dend;
+                int f = 0, fn = 2, p = 0, k1 = 0;
+                if (act) {
+                    f = flags[u];
+                    if (u + 1 < m) fn = flags[u + 1];
+                    p = vcur[u];
+                    k1 = kcur[u];
+                }
+                int gK = wave_incl_max((f & 1) ? (int)u : -1, lane);
+                int gS = wave_incl_max((f & 2) ? (int)u : -1, lane);
+                gK = max(gK, carryK);
+                gS = max(gS, carryS);
+                carryK = __shfl(gK, 63);
+                carryS = __shfl(gS, 63);
+                const bool single = (f & 2) && (fn & 2);
+                if (act) {
+                    const int slot = initial ? (int)u : k1 + ((int)u - gK);
+                    const int nr = initial ? gS : k1 + (gS - gK);
+                    sa[slot] = p;
+                    rk[p] = nr;
+                    if (initial) {
+                        if (!single) atomicOr(&bits[(uint32_t)p >> 5], 1u << (p & 31));
+                    } else if (single) {
+                        atomicAnd(&bits[(uint32_t)p >> 5], ~(1u << (p & 31)));
+                    }
+                }
+                rem += __popcll(__ballot(act && !single));
+            }
+            if (lane == 0) sh.wcount[w] = rem;
+            __syncthreads();
+            int remaining = 0;
+            for (int ww = 0; ww < SA_WAVES; ++ww) remaining += sh.wcount[ww];
+            if (remaining == 0 || h >= N) break;
+        }
+        initial = false;
+        h = (h == 0) ? 1 : h * 2;
+
+        // ---- A: the marked members of the sequence p = SA[j] - h, compacted per wave into valB[cbeg..]
+        {
+            uint32_t wrun = 0;
+            for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                bool a = false;
+                uint32_t p = 0;
+                if (j < cend) {
+                    const uint32_t s = (uint32_t)sa[j];
+                    p = s >= h ? s - h : N - h + s;
+                    a = (bits[p >> 5] >> (p & 31)) & 1u;
+                }
+                const uint64_t bal = __ballot(a);
+                if (a) valB[cbeg + wrun + (uint32_t)__popcll(bal & lanemask_lt(lane))] = (int)p;
+                wrun += (uint32_t)__popcll(bal);
+            }
+            if (lane == 0) sh.wcount[w] = (int)wrun;
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0;
+                for (int ww = 0; ww < SA_WAVES; ++ww) {
+                    sh2.wbase[ww] = acc;
+                    acc += sh.wcount[ww];
+                }
+                sh2.wbase[SA_WAVES] = acc;
+            }
+            hist_clear(sh, tid);
+            __syncthreads();
+            m = (uint32_t)sh2.wbase[SA_WAVES];
+        }
+        const uint32_t Cm = (((m + SA_WAVES - 1) / SA_WAVES) + 63u) & ~63u;
+        dbeg = min((uint32_t)w * Cm, m);
+        dend = min(dbeg + Cm, m);
+
+        // ---- B: dense (rank key, suffix) array in (keyA, valA), fused with the count of digit 0
+        for (uint32_t u0 = dbeg; u0 < dend; u0 += 64) {
+            const uint32_t u = u0 + lane;
+            const bool act = u < dend;
+            int key = 0;
+            if (act) {
+                int sw = 0;  // source wave: wbase[sw] <= u < wbase[sw + 1]
+#pragma unroll
+                for (int ww = 1; ww < SA_WAVES; ++ww) sw += ((uint32_t)sh2.wbase[ww] <= u) ? 1 : 0;
+                const uint32_t sbeg = min((uint32_t)sw * C, N);
+                const int p = valB[sbeg + (u - (uint32_t)sh2.wbase[sw])];
+                key = rk[p];
+                keyA[u] = key;
+                valA[u] = p;
+            }
+            hist_add(sh.hist[w], key & mask, act, lane);
+        }
+        // ---- C: P stable passes over the dense array
+        int32_t *kin = keyA, *vin = valA, *kout = keyB, *vout = valB;
+        for (int pass = 0; pass < P; ++pass) {
+            if (pass > 0) {
+                hist_clear(sh, tid);
+                __syncthreads();
+                count_chunk(sh, kin, dbeg, dend, pass * DB, mask, w, lane);
+            }
+            hist_scan(sh, tid, 1 << DB);
+            scatter_chunk(sh, kin, vin, kout, vout, dbeg, dend, pass * DB, mask, w, lane);
+            __syncthreads();
+            int32_t *t;
+            t = kin; kin = kout; kout = t;
+            t = vin; vin = vout; vout = t;
+        }
+        kcur = kin;
+        vcur = vin;
+    }
+}
+
 // ---- window index: ranks regrouped by the 16 KiB chunk of their position (stable in rank order) ------
 // Lets the match kernel answer "first rank >= lo whose position lies in [i - 2^14, i)" without walking
 // the suffix array: the window meets at most two chunks, and inside a chunk the condition is one-sided.
@@ -403,9 +635,15 @@ void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, con
     hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.samin1, ix.samin2, 1, 1);
 }
 
-void launch_sa_build(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const SaWork &wk, hipStream_t stream) {
+void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
+                     hipStream_t stream) {
     if (n_segs == 0) return;
-    hipLaunchKernelGGL(sa_build_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, d_text, wk);
+    if (max_n + 1 <= SA_BITMAP_MAX_N) {
+        const size_t lds = ((size_t)max_n + 1 + 31) / 32 * 4;
+        hipLaunchKernelGGL(sa_build_kernel, dim3(n_segs), dim3(SA_THREADS), lds, stream, d_segs, d_text, wk);
+    } else {
+        hipLaunchKernelGGL(sa_build_full_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, d_text, wk);
+    }
 }
 
 }  // namespace lzss
