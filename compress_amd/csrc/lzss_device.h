@@ -76,6 +76,24 @@ __device__ inline uint64_t ld8(const uint8_t *p) {
     return v;
 }
 
+// four consecutive int32 / uint16 at any (element-aligned) address in one load
+typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x4_t __attribute__((ext_vector_type(4)));
+struct I4 { i32x4_t v; };
+struct U4 { u16x4_t v; };
+__device__ inline I4 ld_i4(const int32_t *p) {
+    typedef i32x4_t unaligned_t __attribute__((aligned(4)));
+    I4 r;
+    r.v = *reinterpret_cast<const unaligned_t *>(p);
+    return r;
+}
+__device__ inline U4 ld_u4(const uint16_t *p) {
+    typedef u16x4_t unaligned_t __attribute__((aligned(2)));
+    U4 r;
+    r.v = *reinterpret_cast<const unaligned_t *>(p);
+    return r;
+}
+
 // common prefix length of a and b starting from `from`, at most lim; both readable 8 bytes past lim
 __device__ inline int lcp_bytes(const uint8_t *a, const uint8_t *b, int from, int lim) {
     int o = from;

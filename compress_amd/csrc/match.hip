@@ -21,6 +21,8 @@
 //      first in-window entry from lo upward.
 // Positions below HEAD are done by brute force over their (tiny) window instead, because the expected
 // walk length from r to an in-window neighbour grows like n / i.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace lzss {
@@ -146,11 +148,18 @@ __device__ inline uint32_t select_backref(const DictView &D, const uint8_t *T, i
 template <bool LESS>
 __device__ inline int next_thr(const int32_t *P, const int32_t *m1, const int32_t *m2, int j0, int end, int x) {
     int j = j0;
-    while (j < end) {
+    // rest of the current 64-block, four entries per load once j is a multiple of 4
+    while (j < end && (j & 3)) {
         const int v = P[j];
         if (LESS ? v < x : v >= x) return j;
         ++j;
-        if ((j & 63) == 0) break;
+    }
+    while (j < end && (j & 63)) {
+        const I4 q = ld_i4(P + j);  // entries past `end` belong to the padded allocation and are ignored
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (j + t < end && (LESS ? q.v[t] < x : q.v[t] >= x)) return j + t;
+        j += 4;
     }
     if (j >= end) return end;
     int b = j >> 6;
@@ -160,14 +169,25 @@ __device__ inline int next_thr(const int32_t *P, const int32_t *m1, const int32_
             const int v2 = m2[b >> 6];
             if (LESS ? v2 >= x : v2 < x) { b += 64; continue; }
         }
+        if ((b & 3) == 0 && b + 4 <= bend) {  // four block summaries per load
+            const I4 q = ld_i4(m1 + b);
+            int t = 0;
+            for (; t < 4; ++t)
+                if (LESS ? q.v[t] < x : q.v[t] >= x) break;
+            b += t;
+            if (t < 4) break;
+            continue;
+        }
         const int v1 = m1[b];
         if (LESS ? v1 < x : v1 >= x) break;
         ++b;
     }
     if (b >= bend) return end;
-    for (j = b << 6; j < end; ++j) {
-        const int v = P[j];
-        if (LESS ? v < x : v >= x) return j;
+    for (j = b << 6; j < end; j += 4) {
+        const I4 q = ld_i4(P + j);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (j + t < end && (LESS ? q.v[t] < x : q.v[t] >= x)) return j + t;
     }
     return end;
 }
@@ -246,25 +266,187 @@ __device__ inline bool never_queried(const uint8_t *T, int n, int i) {
     return true;
 }
 
-__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, BatchIndex ix, DictView D, uint32_t *res, int skip_unqueried) {
+constexpr int SCAN_CAP = 8;  // x4 ranks a lane walks alone before its wave takes the walk over
+
+__device__ inline int wave_incl_min(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v = t < v ? t : v;
+    }
+    return v;
+}
+
+// One lane per rank.  The walks to the nearest in-window neighbours are short for most ranks and very long
+// for a few (heavy tail), so a lane walks SCAN_CAP x 4 ranks alone; whatever is left is finished by the
+// whole wave, 64 ranks per step (coalesced loads, prefix-min of LCP across lanes, ballot for the first hit).
+__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, BatchIndex ix, DictView D, uint32_t *res,
+                                                              int skip_unqueried, int ablate) {
     const Seg sg = segs[blockIdx.y];
     const int n = (int)sg.n;
     const int N = n + 1;
     if ((int)(blockIdx.x * MATCH_THREADS) >= N) return;
+    const int lane = threadIdx.x & 63;
     const int r = (int)(blockIdx.x * MATCH_THREADS + threadIdx.x);
-    if (r < 1 || r >= N) return;
     const uint8_t *T = ix.text + sg.off;
     const int32_t *SA = ix.sa + sg.off;
     const uint16_t *LCP = ix.lcp + sg.off;
     const uint16_t *b1 = ix.bmin1 + sg.off / 64;
     const uint16_t *b2 = ix.bmin2 + sg.off / 64;
 
-    const int i = SA[r];
-    if (i < (int)sg.start || i < HEAD) return;
-    if (skip_unqueried && never_queried(T, n, i)) {
-        res[sg.off + i] = res_pack(RES_NONE, 0, 0);
-        return;
+    bool work = r >= 1 && r < N;
+    int i = 0;
+    if (work) {
+        i = SA[r];
+        work = !(i < (int)sg.start || i < HEAD);
     }
+    if (work && skip_unqueried && never_queried(T, n, i)) {
+        res[sg.off + i] = res_pack(RES_NONE, 0, 0);
+        work = false;
+    }
+    const int maxLen = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
+    const bool reserved = work && T[i] >= LZSS_SYMBOL_SHORT;
+    const int minS = reserved ? 1 : LZSS_SHORT_MIN_LEN;
+    const int minD = reserved ? 1 : LZSS_DYN_MIN_LEN;
+    const bool shortOK = maxLen >= minS, dynOK = maxLen >= minD;
+    const int wsS = i > LZSS_SHORT_WINDOW ? i - LZSS_SHORT_WINDOW : 0;
+    const int wsL = i > LZSS_DYN_WINDOW ? i - LZSS_DYN_WINDOW : 0;
+    const bool scan = work && shortOK && !(ablate & 4);
+
+    int LupS = 0, pupS = -1, LupL = 0, pupL = -1;
+    int LdnS = 0, kdnS = -1, LdnL = 0, kdnL = -1;
+
+    // ---- nearest in-window neighbours above r (the arrays are padded past N)
+    {
+        int m = 1 << 20, k = r + 1;
+        bool fL = false, done = !scan;
+        for (int it = 0; it < SCAN_CAP && !done && k < N; ++it, k += 4) {
+            const I4 sa4 = ld_i4(SA + k);
+            const U4 l4 = ld_u4(LCP + k);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (done || k + t >= N) { done = true; continue; }
+                const int l = l4.v[t];
+                m = l < m ? l : m;
+                if (m < minS) { done = true; continue; }
+                const int p = sa4.v[t];
+                if (p < i) {
+                    if (!fL && p >= wsL) { fL = true; LupL = m; pupL = p; }
+                    if (p >= wsS) { LupS = m; pupS = p; done = true; }
+                }
+            }
+        }
+        if (k >= N) done = true;
+        for (uint64_t hm = __ballot(!done); hm; hm &= hm - 1) {  // the wave finishes lane t's walk
+            const int t = (int)__builtin_ctzll(hm);
+            const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
+            int cm = __shfl(m, t);
+            bool cfL = __shfl((int)fL, t) != 0;
+            int rLL = 0, rpL = -1, rLS = 0, rpS = -1;
+            bool gotL = false;
+            for (int base = __shfl(k, t); base < N; base += 64) {
+                const int kk = base + lane;
+                const bool valid = kk < N;
+                const int l = valid ? (int)LCP[kk] : 0;
+                const int p = valid ? SA[kk] : 0x7FFFFFFF;
+                int pm = wave_incl_min(l, lane);
+                pm = pm < cm ? pm : cm;
+                const bool alive = pm >= cmin;
+                const uint64_t bL = __ballot(alive && p < ci && p >= cwl);
+                const uint64_t bS = __ballot(alive && p < ci && p >= cws);
+                const uint64_t bDead = __ballot(!alive);
+                if (!cfL && bL) {
+                    const int t2 = (int)__builtin_ctzll(bL);
+                    rLL = __shfl(pm, t2); rpL = __shfl(p, t2);
+                    cfL = true; gotL = true;
+                }
+                if (bS) {
+                    const int t2 = (int)__builtin_ctzll(bS);
+                    rLS = __shfl(pm, t2); rpS = __shfl(p, t2);
+                    break;
+                }
+                if (bDead) break;
+                cm = __shfl(pm, 63);
+            }
+            if (lane == t) {
+                if (gotL) { LupL = rLL; pupL = rpL; }
+                LupS = rLS; pupS = rpS;
+            }
+        }
+    }
+    // ---- nearest in-window neighbours below r: lcp(i, SA[k]) = min LCP[k+1 .. r]; rank 0 is the sentinel
+    {
+        int m = 1 << 20, k = r - 1, it = 0;
+        bool fL = false, done = !scan;
+        for (; k >= 4 && !done && it < SCAN_CAP; k -= 4, ++it) {  // ranks k, k-1, k-2, k-3
+            const I4 sa4 = ld_i4(SA + k - 3);
+            const U4 l4 = ld_u4(LCP + k - 2);
+#pragma unroll
+            for (int t = 3; t >= 0; --t) {
+                if (done) continue;
+                const int l = l4.v[t];
+                m = l < m ? l : m;
+                if (m < minS) { done = true; continue; }
+                const int p = sa4.v[t];
+                if (p < i) {
+                    const int kk = k - 3 + t;
+                    if (!fL && p >= wsL) { fL = true; LdnL = m; kdnL = kk; }
+                    if (p >= wsS) { LdnS = m; kdnS = kk; done = true; }
+                }
+            }
+        }
+        if (!done && k < 4) {
+            for (; k >= 1 && !done; --k) {
+                const int l = LCP[k + 1];
+                m = l < m ? l : m;
+                if (m < minS) break;
+                const int p = SA[k];
+                if (p < i) {
+                    if (!fL && p >= wsL) { fL = true; LdnL = m; kdnL = k; }
+                    if (p >= wsS) { LdnS = m; kdnS = k; break; }
+                }
+            }
+            done = true;
+        }
+        for (uint64_t hm = __ballot(!done); hm; hm &= hm - 1) {
+            const int t = (int)__builtin_ctzll(hm);
+            const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
+            int cm = __shfl(m, t);
+            bool cfL = __shfl((int)fL, t) != 0;
+            int rLL = 0, rkL = -1, rLS = 0, rkS = -1;
+            bool gotL = false;
+            for (int base = __shfl(k, t); base >= 1; base -= 64) {
+                const int kk = base - lane;
+                const bool valid = kk >= 1;
+                const int l = valid ? (int)LCP[kk + 1] : 0;
+                const int p = valid ? SA[kk] : 0x7FFFFFFF;
+                int pm = wave_incl_min(l, lane);
+                pm = pm < cm ? pm : cm;
+                const bool alive = pm >= cmin;
+                const uint64_t bL = __ballot(alive && p < ci && p >= cwl);
+                const uint64_t bS = __ballot(alive && p < ci && p >= cws);
+                const uint64_t bDead = __ballot(!alive);
+                if (!cfL && bL) {
+                    const int t2 = (int)__builtin_ctzll(bL);
+                    rLL = __shfl(pm, t2); rkL = base - t2;
+                    cfL = true; gotL = true;
+                }
+                if (bS) {
+                    const int t2 = (int)__builtin_ctzll(bS);
+                    rLS = __shfl(pm, t2); rkS = base - t2;
+                    break;
+                }
+                if (bDead) break;
+                cm = __shfl(pm, 63);
+            }
+            if (lane == t) {
+                if (gotL) { LdnL = rLL; kdnL = rkL; }
+                LdnS = rLS; kdnS = rkS;
+            }
+        }
+    }
+    if (!work) return;
+
     SegIndex S;
     S.SA = SA; S.LCP = LCP; S.b1 = b1; S.b2 = b2;
     S.KS = ix.ks + sg.off; S.PS = ix.ps + sg.off;
@@ -272,60 +454,21 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
     S.pmin2 = ix.pmin2 + sg.off / 64; S.pmax2 = ix.pmax2 + sg.off / 64;
     S.samin1 = ix.samin1 + sg.off / 64; S.samin2 = ix.samin2 + sg.off / 64;
     S.n = n;
-
-    const int maxLen = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
-    const bool reserved = T[i] >= LZSS_SYMBOL_SHORT;
-    const int minS = reserved ? 1 : LZSS_SHORT_MIN_LEN;
-    const int minD = reserved ? 1 : LZSS_DYN_MIN_LEN;
-    const bool shortOK = maxLen >= minS, dynOK = maxLen >= minD;
-    const int wsS = i > LZSS_SHORT_WINDOW ? i - LZSS_SHORT_WINDOW : 0;
-    const int wsL = i > LZSS_DYN_WINDOW ? i - LZSS_DYN_WINDOW : 0;
-
-    int LupS = 0, pupS = -1, LupL = 0, pupL = -1;
-    int LdnS = 0, kdnS = -1, LdnL = 0, kdnL = -1;
-    if (shortOK) {
-        // nearest in-window neighbours above r
-        int m = 1 << 20;
-        bool fL = false;
-        for (int k = r + 1; k < N; ++k) {
-            const int l = LCP[k];
-            m = l < m ? l : m;
-            if (m < minS) break;
-            const int p = SA[k];
-            if (p < i) {
-                if (!fL && p >= wsL) { fL = true; LupL = m; pupL = p; }
-                if (p >= wsS) { LupS = m; pupS = p; break; }
-            }
-        }
-        // nearest in-window neighbours below r (rank 0 is the sentinel: lcp 0)
-        m = 1 << 20;
-        fL = false;
-        for (int k = r - 1; k >= 1; --k) {
-            const int l = LCP[k + 1];
-            m = l < m ? l : m;
-            if (m < minS) break;
-            const int p = SA[k];
-            if (p < i) {
-                if (!fL && p >= wsL) { fL = true; LdnL = m; kdnL = k; }
-                if (p >= wsS) { LdnS = m; kdnS = k; break; }
-            }
-        }
-    }
     // short window
     int Ls = 0, ps = -1;
     {
         const int ld = LdnS >= minS ? LdnS : 0, lu = LupS >= minS ? LupS : 0;
         Ls = ld > lu ? ld : lu;
-        if (Ls > 0) ps = (lu > ld) ? pupS : leftmost_short(S, kdnS, Ls, wsS, i);
+        if (Ls > 0) ps = (lu > ld) ? pupS : ((ablate & 2) ? SA[kdnS] : leftmost_short(S, kdnS, Ls, wsS, i));
     }
     // long window
     int LL = 0, pL = -1;
     if (dynOK) {
         const int ld = LdnL >= minD ? LdnL : 0, lu = LupL >= minD ? LupL : 0;
         LL = ld > lu ? ld : lu;
-        if (LL > 0) pL = (lu > ld) ? pupL : leftmost_long(S, kdnL, LL, wsL, i);
+        if (LL > 0) pL = (lu > ld) ? pupL : ((ablate & 2) ? SA[kdnL] : leftmost_long(S, kdnL, LL, wsL, i));
     }
-    res[sg.off + i] = select_backref(D, T, i, maxLen, minD, dynOK, Ls, ps, LL, pL);
+    res[sg.off + i] = select_backref(D, T, i, maxLen, minD, dynOK && !(ablate & 1), Ls, ps, LL, pL);
 }
 
 // positions i < HEAD: brute force over the window [0, i) (identical for both window sizes there)
@@ -365,7 +508,8 @@ void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const Batc
     hipLaunchKernelGGL(match_head_kernel, gh, dim3(64), 0, stream, d_segs, ix, dict, d_res);
     if (max_n > (uint32_t)HEAD) {
         dim3 g((max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS, n_segs);
-        hipLaunchKernelGGL(match_kernel, g, dim3(MATCH_THREADS), 0, stream, d_segs, ix, dict, d_res, skip_unqueried ? 1 : 0);
+        static const int ablate = getenv("MI355_LZSS_ABLATE") ? atoi(getenv("MI355_LZSS_ABLATE")) : 0;  // timing experiments only
+        hipLaunchKernelGGL(match_kernel, g, dim3(MATCH_THREADS), 0, stream, d_segs, ix, dict, d_res, skip_unqueried ? 1 : 0, ablate);
     }
 }
 
