@@ -108,30 +108,51 @@ __device__ inline int lcp_bytes(const uint8_t *a, const uint8_t *b, int from, in
     return o < lim ? o : lim;
 }
 
+typedef uint16_t u16x8_t __attribute__((ext_vector_type(8)));
+
+// largest index <= j inside the 8-aligned group of j whose value is < L, or -1 (one 16-byte load)
+__device__ inline int scan_down8(const uint16_t *A, int j, int L) {
+    const int g = j & ~7;
+    typedef u16x8_t unaligned_t __attribute__((aligned(2)));
+    const u16x8_t q = *reinterpret_cast<const unaligned_t *>(A + g);
+    int found = -1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t <= j - g && (int)q[t] < L) found = g + t;
+    return found;
+}
+
 // largest j <= k with LCP[j] < L (L >= 1; LCP[0] == 0 guarantees one exists): the first rank of
-// the interval of suffixes sharing >= L bytes with the suffix of rank k.
+// the interval of suffixes sharing >= L bytes with the suffix of rank k.  Two levels of block minima
+// (64 and 4096 ranks) and 8 entries per load keep this at a handful of dependent loads.
 __device__ inline int prev_lower(const uint16_t *LCP, const uint16_t *bmin1, const uint16_t *bmin2, int k, int L) {
     int j = k;
-    for (;;) {
-        if ((int)LCP[j] < L) return j;
-        if ((j & 63) == 0) break;
-        --j;
+    for (;;) {  // rest of k's 64-block
+        const int f = scan_down8(LCP, j, L);
+        if (f >= 0) return f;
+        j = (j & ~7) - 1;
+        if (((j + 1) & 63) == 0) break;
     }
-    if (j == 0) return 0;  // cannot happen (LCP[0] == 0 < L); keeps every loop below bounded
-    int b = (j >> 6) - 1;  // j is a block start with LCP[j] >= L, so j >= 64 here
-    while (b > 0) {
-        if ((int)bmin1[b] < L) break;
-        if ((b & 63) == 0) {
-            int c = (b >> 6) - 1;
+    if (j < 0) return 0;  // cannot happen (LCP[0] == 0 < L); keeps the loops below bounded
+    int b = j >> 6;       // last block not yet examined
+    for (;;) {
+        const int f = scan_down8(bmin1, b, L);
+        if (f >= 0) { b = f; break; }
+        b = (b & ~7) - 1;
+        if (b < 0) { b = 0; break; }
+        if (((b + 1) & 63) == 0) {  // a whole superblock boundary: skip superblocks without a hit
+            int c = b >> 6;
             while (c > 0 && (int)bmin2[c] >= L) --c;
             b = c * 64 + 63;
-            continue;
         }
-        --b;
     }
     j = b * 64 + 63;
-    while (j > 0 && (int)LCP[j] >= L) --j;
-    return j;
+    for (;;) {
+        const int f = scan_down8(LCP, j, L);
+        if (f >= 0) return f;
+        j = (j & ~7) - 1;
+        if (j < 0) return 0;
+    }
 }
 
 }  // namespace lzss
