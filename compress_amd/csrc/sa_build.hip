@@ -14,6 +14,8 @@
 // suffixes p >= N - h, whose first h symbols contain the sentinel and which are therefore already
 // alone in their group, so their place in the sequence does not matter: p = N - h + SA[j] keeps the
 // sequence a permutation of 0..N-1.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace lzss {
@@ -319,7 +321,22 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_full_kernel(const Seg *se
 //   D  boundaries of (old group, second key) give every active suffix its new group start and its slot in
 //      the suffix array (old group start + index inside the group); suffixes now alone leave the bitmap.
 // Suffixes that are alone in their group never move again, so SA and the ranks are updated in place.
-constexpr uint32_t SA_BITMAP_MAX_N = 300000;  // bitmap words live in dynamic LDS
+constexpr uint32_t SA_BITMAP_MAX_N = 300000;
+constexpr int SA_INIT_SYMS = 4;  // depth of the initial sort (symbols compared straight from the text)
+
+// the first SA_INIT_SYMS symbols of suffix p as two integers (high half, low half), sentinel-aware
+__device__ inline void init_keys(const uint8_t *T, uint32_t n, uint32_t p, int &k1, int &k2) {
+    uint32_t s[SA_INIT_SYMS];
+#pragma unroll
+    for (int t = 0; t < SA_INIT_SYMS; ++t) s[t] = (p + t < n) ? (uint32_t)T[p + t] + 1u : 0u;
+    uint32_t hi = 0, lo = 0;
+#pragma unroll
+    for (int t = 0; t < SA_INIT_SYMS / 2; ++t) hi = (hi << 9) | s[t];
+#pragma unroll
+    for (int t = SA_INIT_SYMS / 2; t < SA_INIT_SYMS; ++t) lo = (lo << 9) | s[t];
+    k1 = (int)hi;
+    k2 = (int)lo;
+}  // bitmap words live in dynamic LDS
 
 struct SaShared2 {
     SaShared s;
@@ -327,7 +344,7 @@ struct SaShared2 {
     int32_t wlastS[SA_WAVES];
 };
 
-__global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk) {
+__global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
     __shared__ SaShared2 sh2;
     extern __shared__ uint32_t bits[];
     SaShared &sh = sh2.s;
@@ -358,25 +375,52 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
 
     for (uint32_t x = tid; x < (N + 31) / 32; x += SA_THREADS) bits[x] = 0;
 
-    // ---- initial order by first symbol (full pass)
-    hist_clear(sh, tid);
-    __syncthreads();
-    for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool active = j < cend;
-        int key = 0;
-        if (active) {
-            key = j < n ? (int)T[j] + 1 : 0;
-            keyA[j] = key;
-            valA[j] = (int)j;
+    // ---- initial order by the first SA_INIT_SYMS symbols (0 = sentinel, byte + 1 otherwise): LSD passes
+    //      whose digit is read from the text, so only the suffix numbers move (4 bytes per element)
+    {
+        const int32_t *vin = nullptr;  // pass 0 reads the identity
+        int32_t *vout = valA;
+        for (int pass = 0; pass < SA_INIT_SYMS; ++pass) {
+            const uint32_t d = (uint32_t)(SA_INIT_SYMS - 1 - pass);  // symbol index used by this pass
+            int32_t *hrow = sh.hist[w];
+            hist_clear(sh, tid);
+            __syncthreads();
+            for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool active = j < cend;
+                int key = 0;
+                if (active) {
+                    const uint32_t q = (vin ? (uint32_t)vin[j] : j) + d;
+                    key = q < n ? (int)T[q] + 1 : 0;
+                }
+                hist_add(hrow, key, active, lane);
+            }
+            hist_scan(sh, tid, SA_BINS);
+            for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool active = j < cend;
+                int key = 0, val = 0;
+                if (active) {
+                    val = vin ? vin[j] : (int)j;
+                    const uint32_t q = (uint32_t)val + d;
+                    key = q < n ? (int)T[q] + 1 : 0;
+                }
+                const uint64_t amask = __ballot(active);
+                const uint64_t peers = match_digit(key, amask);
+                const int cnt = __popcll(peers);
+                const int rank = __popcll(peers & lanemask_lt(lane));
+                const int base = hrow[key];
+                if (active) vout[base + rank] = val;
+                __builtin_amdgcn_wave_barrier();
+                if (active && rank == cnt - 1) hrow[key] = base + cnt;
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+            vin = vout;
+            vout = (vout == valA) ? valB : valA;
         }
-        hist_add(sh.hist[w], key, active, lane);
     }
-    hist_scan(sh, tid, SA_BINS);
-    scatter_chunk(sh, keyA, valA, keyB, valB, cbeg, cend, 0, SA_BINS - 1, w, lane);
-    __syncthreads();
-
-    const int32_t *kcur = keyB, *vcur = valB;  // sorted (key, suffix) of the current round, dense
+    const int32_t *kcur = keyB, *vcur = (SA_INIT_SYMS & 1) ? valA : valB;
     uint32_t m = N;                            // its length
     uint32_t dbeg = cbeg, dend = cend;         // this wave's chunk of it
     uint32_t h = 0;
@@ -392,16 +436,24 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
                 int p = 0, k1 = -2, k2 = -1;
                 if (act) {
                     p = vcur[u];
-                    k1 = kcur[u];
-                    if (!initial && (uint32_t)p + h < N) k2 = rk[(uint32_t)p + h];
+                    if (initial) {
+                        init_keys(T, n, (uint32_t)p, k1, k2);
+                    } else {
+                        k1 = kcur[u];
+                        if ((uint32_t)p + h < N) k2 = rk[(uint32_t)p + h];
+                    }
                 }
                 int q1 = __shfl_up(k1, 1), q2 = __shfl_up(k2, 1);
                 if (lane == 0) {
                     if (u0 == dbeg) {
                         if (u > 0) {
                             const int pp = vcur[u - 1];
-                            q1 = kcur[u - 1];
-                            q2 = (!initial && (uint32_t)pp + h < N) ? rk[(uint32_t)pp + h] : -1;
+                            if (initial) {
+                                init_keys(T, n, (uint32_t)pp, q1, q2);
+                            } else {
+                                q1 = kcur[u - 1];
+                                q2 = ((uint32_t)pp + h < N) ? rk[(uint32_t)pp + h] : -1;
+                            }
                         } else {
                             q1 = -3;
                         }
@@ -438,7 +490,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
                     f = flags[u];
                     if (u + 1 < m) fn = flags[u + 1];
                     p = vcur[u];
-                    k1 = kcur[u];
+                    if (!initial) k1 = kcur[u];
                 }
                 int gK = wave_incl_max((f & 1) ? (int)u : -1, lane);
                 int gS = wave_incl_max((f & 2) ? (int)u : -1, lane);
@@ -464,10 +516,10 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
             __syncthreads();
             int remaining = 0;
             for (int ww = 0; ww < SA_WAVES; ++ww) remaining += sh.wcount[ww];
-            if (remaining == 0 || h >= N) break;
+            if (remaining == 0 || h >= N || --max_rounds < 0) break;
         }
         initial = false;
-        h = (h == 0) ? 1 : h * 2;
+        h = (h == 0) ? (uint32_t)SA_INIT_SYMS : h * 2;
 
         // ---- A: the marked members of the sequence p = SA[j] - h, compacted per wave into valB[cbeg..]
         {
@@ -640,7 +692,8 @@ void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const u
     if (n_segs == 0) return;
     if (max_n + 1 <= SA_BITMAP_MAX_N) {
         const size_t lds = ((size_t)max_n + 1 + 31) / 32 * 4;
-        hipLaunchKernelGGL(sa_build_kernel, dim3(n_segs), dim3(SA_THREADS), lds, stream, d_segs, d_text, wk);
+        static const int max_rounds = getenv("MI355_LZSS_SA_ROUNDS") ? atoi(getenv("MI355_LZSS_SA_ROUNDS")) : 1000;  // timing experiments only
+        hipLaunchKernelGGL(sa_build_kernel, dim3(n_segs), dim3(SA_THREADS), lds, stream, d_segs, d_text, wk, max_rounds);
     } else {
         hipLaunchKernelGGL(sa_build_full_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, d_text, wk);
     }
