@@ -18,7 +18,7 @@
 namespace lzss {
 
 constexpr int DECIDE_THREADS = 256;
-constexpr int WALK_THREADS = 512;
+constexpr int WALK_THREADS = 256;
 constexpr int TILE = 256;  // must be >= the largest advance (1 << maxBackrefLenLog2)
 
 __device__ inline int savings_of(uint32_t r) {  // backref.savings, lzss/backref.go:88-93
@@ -93,59 +93,97 @@ void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uin
 }
 
 // ---- walk: visited tiles, per-tile bit offsets, per-blob size -------------------------------------
+// Groups of WG_TILES tiles are staged in LDS with coalesced 16-byte loads (adv, kind) so that the
+// per-tile sequential passes below never touch HBM byte by byte.  Tile tl's byte x lives at dword
+// ((x / 4 + tl) mod 64) of its 256-byte row: lanes (= tiles) that work on the same x hit 64 different banks.
+constexpr int WG_TILES = 128;
+
+__device__ inline uint32_t tile_idx(int tl, int x) { return (uint32_t)(tl * 256 + ((((x >> 2) + tl) & 63) << 2) + (x & 3)); }
+
 __global__ __launch_bounds__(WALK_THREADS) void walk_kernel(const Seg *segs, WalkWork ww, uint32_t header_bytes,
                                                             uint32_t bit_off) {
+    __shared__ uint32_t s_adv32[WG_TILES * 64], s_kind32[WG_TILES * 64], s_exit32[WG_TILES * 64];
+    __shared__ uint16_t s_entry[WG_TILES];
     __shared__ uint64_t s_wave[WALK_THREADS / 64];
     __shared__ uint64_t s_carry;
+    __shared__ int s_e;
+    uint8_t *s_adv = (uint8_t *)s_adv32, *s_kind = (uint8_t *)s_kind32, *s_exit = (uint8_t *)s_exit32;
     const Seg sg = segs[blockIdx.x];
     const int n = (int)sg.n, start = (int)sg.start;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint8_t *adv = ww.adv + sg.off;
     const uint8_t *kind = ww.kind + sg.off;
-    uint8_t *exitoff = ww.exitoff + sg.off;
     uint16_t *entry = ww.entry + sg.off / TILE;
     uint64_t *tilebit = ww.tilebit + sg.off / TILE;
     const int ntiles = (n + TILE - 1) / TILE;
     const int t0 = start / TILE;
-
-    // (A) for every position: where the chain from it first lands beyond its tile
-    for (int t = t0 + tid; t < ntiles; t += WALK_THREADS) {
-        const int tend = (t + 1) * TILE;
-        const int hi = tend < n ? tend : n;
-        const int lo = t * TILE > start ? t * TILE : start;
-        for (int i = hi - 1; i >= lo; --i) {
-            const int nx = i + (int)adv[i] + 1;
-            uint8_t e;
-            if (nx >= tend) e = (uint8_t)(nx - tend);
-            else if (nx >= n) e = 0;
-            else e = exitoff[nx];
-            exitoff[i] = e;
-        }
-        entry[t] = 0xFFFFu;
+    if (tid == 0) {
+        s_carry = 0;
+        s_e = start;
     }
-    __syncthreads();
-    // (B) hop from tile to tile
-    if (tid == 0 && start < n) {
-        int e = start;
-        for (int t = t0;; ++t) {
-            entry[t] = (uint16_t)(e - t * TILE);
-            if (t + 1 >= ntiles) break;
-            e = (t + 1) * TILE + (int)exitoff[e];
-            if (e >= n) break;
+    for (int g0 = t0; g0 < ntiles; g0 += WG_TILES) {
+        const int gt = (ntiles - g0) < WG_TILES ? (ntiles - g0) : WG_TILES;
+        __syncthreads();
+        // stage adv / kind of the group's tiles (the arrays are padded, reading past n is harmless)
+        for (int c = tid; c < gt * 16; c += WALK_THREADS) {
+            const int tl = c >> 4, x0 = (c & 15) * 16;
+            const size_t gpos = (size_t)(g0 + tl) * TILE + x0;
+            const uint4 va = *reinterpret_cast<const uint4 *>(adv + gpos);
+            const uint4 vk = *reinterpret_cast<const uint4 *>(kind + gpos);
+            const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, k4[4] = {vk.x, vk.y, vk.z, vk.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t di = (uint32_t)(tl * 64 + (((x0 >> 2) + d + tl) & 63));
+                s_adv32[di] = a4[d];
+                s_kind32[di] = k4[d];
+            }
         }
-    }
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    // (C) bits per tile, exclusive scan in tile order
-    for (int tb = t0; tb < ntiles; tb += WALK_THREADS) {
-        const int t = tb + tid;
+        __syncthreads();
+        // (A) for every position of my tile: where the chain from it first lands beyond the tile
+        if (tid < gt) {
+            const int tl = tid, t = g0 + tl;
+            const int tend = (t + 1) * TILE;
+            const int hi = tend < n ? tend : n;
+            const int lo = t * TILE > start ? t * TILE : start;
+            for (int i = hi - 1; i >= lo; --i) {
+                const int nx = i + (int)s_adv[tile_idx(tl, i & 255)] + 1;
+                uint8_t e;
+                if (nx >= tend) e = (uint8_t)(nx - tend);
+                else if (nx >= n) e = 0;
+                else e = s_exit[tile_idx(tl, nx & 255)];
+                s_exit[tile_idx(tl, i & 255)] = e;
+            }
+        }
+        __syncthreads();
+        // (B) hop from tile to tile
+        if (tid == 0) {
+            int e = s_e;
+            for (int tl = 0; tl < gt; ++tl) {
+                const int t = g0 + tl;
+                if (e >= n || (e >> 8) != t) {
+                    s_entry[tl] = 0xFFFFu;
+                } else {
+                    s_entry[tl] = (uint16_t)(e & 255);
+                    e = (t + 1) * TILE + (int)s_exit[tile_idx(tl, e & 255)];
+                }
+            }
+            s_e = e;
+        }
+        __syncthreads();
+        // (C) bits per tile, exclusive scan in tile order
         uint64_t bits = 0;
-        if (t < ntiles) {
-            const uint32_t e = entry[t];
-            if (e != 0xFFFFu) {
+        uint32_t ent = 0xFFFFu;
+        if (tid < gt) {
+            const int tl = tid, t = g0 + tl;
+            ent = s_entry[tl];
+            if (ent != 0xFFFFu) {
                 const int tend = (t + 1) * TILE;
                 const int hi = tend < n ? tend : n;
-                for (int i = t * TILE + (int)e; i < hi; i += (int)adv[i] + 1) bits += kind_bits(kind[i]);
+                for (int i = t * TILE + (int)ent; i < hi;) {
+                    const uint32_t ix = tile_idx(tl, i & 255);
+                    bits += kind_bits(s_kind[ix]);
+                    i += (int)s_adv[ix] + 1;
+                }
             }
         }
         uint64_t inc = bits;
@@ -158,11 +196,14 @@ __global__ __launch_bounds__(WALK_THREADS) void walk_kernel(const Seg *segs, Wal
         __syncthreads();
         uint64_t base = s_carry;
         for (int ww2 = 0; ww2 < w; ++ww2) base += s_wave[ww2];
-        if (t < ntiles) tilebit[t] = (uint64_t)bit_off + base + inc - bits;
+        if (tid < gt) {
+            tilebit[g0 + tid] = (uint64_t)bit_off + base + inc - bits;
+            entry[g0 + tid] = (uint16_t)ent;
+        }
         __syncthreads();
         if (tid == WALK_THREADS - 1) s_carry = base + inc;
-        __syncthreads();
     }
+    __syncthreads();
     if (tid == 0) {
         const uint64_t total = s_carry;
         ww.nbits[blockIdx.x] = total;
