@@ -20,7 +20,13 @@ struct DictView {     // the dictionary index of a ctx (device pointers)
     uint32_t n;
     const int32_t *SA;
     const uint16_t *LCP, *bmin1, *bmin2;
+    const uint64_t *key;       // [rank] first 8 bytes of the suffix, big-endian, zero padded
+    const int32_t *bstart;     // [first two bytes] rank range [bstart, bend) of the suffixes starting with them
+    const int32_t *bend;
 };
+// fills key / bstart / bend (bstart, bend must be zeroed) from the dictionary's text and suffix array
+void launch_dict_aux(const uint8_t *d_text, uint32_t n, const int32_t *d_sa, uint64_t *d_key, int32_t *d_bstart,
+                     int32_t *d_bend, hipStream_t stream);
 struct BatchIndex {   // batch-wide index arrays
     const uint8_t *text;
     int32_t *sa, *isa;

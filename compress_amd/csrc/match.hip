@@ -87,31 +87,92 @@ void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchI
 }
 
 // ---- dictionary lookup (compress.go:463: LookupLongest over [0, dictLen)) -----------------------
+// Auxiliary arrays of the dictionary index: an 8-byte big-endian prefix key per rank (one load decides
+// almost every probe of the binary search) and the rank range of every two-byte prefix (skips the first
+// probes altogether).
+__global__ __launch_bounds__(256) void dict_aux_kernel(const uint8_t *T, uint32_t n, const int32_t *SA, uint64_t *key,
+                                                       int32_t *bstart, int32_t *bend) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;  // rank, 0 = sentinel
+    if (k > n) return;
+    const uint32_t q = (uint32_t)SA[k];
+    key[k] = __builtin_bswap64(ld8(T + q));  // the text is zero padded past n
+    if (k == 0 || q + 2 > n) return;
+    const uint32_t b = ((uint32_t)T[q] << 8) | T[q + 1];
+    const uint32_t qp = (uint32_t)SA[k - 1];
+    const bool first = (k == 1) || qp + 2 > n || ((((uint32_t)T[qp] << 8) | T[qp + 1]) != b);
+    if (first) bstart[b] = (int32_t)k;
+    bool last = (k == n);
+    if (!last) {
+        const uint32_t qn = (uint32_t)SA[k + 1];
+        last = qn + 2 > n || ((((uint32_t)T[qn] << 8) | T[qn + 1]) != b);
+    }
+    if (last) bend[b] = (int32_t)k + 1;
+}
+
+void launch_dict_aux(const uint8_t *d_text, uint32_t n, const int32_t *d_sa, uint64_t *d_key, int32_t *d_bstart,
+                     int32_t *d_bend, hipStream_t stream) {
+    hipLaunchKernelGGL(dict_aux_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, stream, d_text, n, d_sa, d_key, d_bstart,
+                       d_bend);
+}
+
+// exact common prefix of pat[0:maxLen) and the dictionary suffix of rank k (0 for the sentinel / virtual ranks)
+__device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen, int k, int from) {
+    if (k < 1 || k > (int)D.n) return 0;
+    const int q = D.SA[k];
+    const int avail = (int)D.n - q;
+    return lcp_bytes(pat, D.T + q, from, maxLen < avail ? maxLen : avail);
+}
+
 // Longest prefix of pat[0:maxLen) occurring in the dictionary, and its smallest-rank occurrence.
-__device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int maxLen, int &Ld, int &pd) {
+// minLen: shorter results are of no use to the caller (lets an empty two-byte bucket end the search).
+__device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int maxLen, int minLen, int &Ld, int &pd, int g_ablate) {
+    Ld = 0;
+    pd = -1;
     // invariant: suffix(lo) < pat <= suffix(hi); rank 0 is the sentinel, rank n+1 is virtual
     int lo = 0, hi = (int)D.n + 1;
-    int llo = 0, lhi = 0;
+    if (maxLen >= 2) {
+        const uint32_t b = ((uint32_t)pat[0] << 8) | pat[1];
+        const int s = D.bstart[b], e = D.bend[b];
+        if (s < e) {  // every suffix sharing two bytes with pat is in [s, e)
+            lo = s - 1;
+            hi = e;
+        } else if (minLen >= 2) {
+            return;  // nothing in the dictionary shares two bytes with pat
+        }
+    }
+    uint64_t pk = __builtin_bswap64(ld8(pat));
+    if (maxLen < 8) pk &= ~0ull << (8 * (8 - maxLen));
+    int llo = 0, lhi = 0;  // lower bounds of lcp(pat, suffix(lo)) / lcp(pat, suffix(hi)), exact when set by a text compare
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        const int q = D.SA[mid];
-        const int avail = (int)D.n - q;
-        const int lim = maxLen < avail ? maxLen : avail;
-        int o = llo < lhi ? llo : lhi;
-        o = lcp_bytes(pat, D.T + q, o, lim);
+        const uint64_t kq = D.key[mid];
         bool suffix_less;
-        if (o == maxLen) suffix_less = false;          // pat is a prefix of the suffix
-        else if (o == avail) suffix_less = true;       // the suffix is a proper prefix of pat
-        else suffix_less = D.T[q + o] < pat[o];
+        int o = 0;
+        if (kq != pk) {
+            suffix_less = kq < pk;  // padding zeros never make a key larger, so the key order is the suffix order
+        } else if (g_ablate & 16) {
+            suffix_less = false;
+        } else {
+            const int q = D.SA[mid];
+            const int avail = (int)D.n - q;
+            const int lim = maxLen < avail ? maxLen : avail;
+            o = llo < lhi ? llo : lhi;
+            const int o8 = lim < 8 ? lim : 8;
+            o = lcp_bytes(pat, D.T + q, o > o8 ? o : o8, lim);
+            if (o == maxLen) suffix_less = false;          // pat is a prefix of the suffix
+            else if (o == avail) suffix_less = true;       // the suffix is a proper prefix of pat
+            else suffix_less = D.T[q + o] < pat[o];
+        }
         if (suffix_less) { lo = mid; llo = o; } else { hi = mid; lhi = o; }
     }
+    llo = dict_lcp(D, pat, maxLen, lo, llo);
+    lhi = dict_lcp(D, pat, maxLen, hi, lhi);
     Ld = llo > lhi ? llo : lhi;
-    pd = -1;
     if (Ld <= 0) return;
     if (lhi > llo) {
         pd = D.SA[hi];  // nothing below hi shares Ld bytes
     } else {
-        const int lo2 = prev_lower(D.LCP, D.bmin1, D.bmin2, lo, Ld);
+        const int lo2 = (g_ablate & 8) ? lo : prev_lower(D.LCP, D.bmin1, D.bmin2, lo, Ld);
         pd = D.SA[lo2];
     }
 }
@@ -119,7 +180,7 @@ __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int ma
 // Combine the data-window results with the dictionary and apply the selection rule of
 // compress.go:160-169.  Ls/ps: short window, LL/pL: long window (0 / -1 = none).
 __device__ inline uint32_t select_backref(const DictView &D, const uint8_t *T, int i, int maxLen, int minD, bool dynOK,
-                                          int Ls, int ps, int LL, int pL) {
+                                          int Ls, int ps, int LL, int pL, int ablate = 0) {
     int Ldyn = 0;
     uint32_t fdyn = 0;
     if (dynOK) {
@@ -129,7 +190,7 @@ __device__ inline uint32_t select_backref(const DictView &D, const uint8_t *T, i
         }
         if (LL < maxLen) {  // compress.go:460: the dictionary is consulted only then
             int Ld, pd;
-            dict_lookup(D, T + i, maxLen, Ld, pd);
+            dict_lookup(D, T + i, maxLen, minD, Ld, pd, ablate);
             if (Ld >= minD && Ld > LL) {  // compress.go:464: strictly longer
                 Ldyn = Ld;
                 fdyn = (uint32_t)(i + (int)D.n - pd - 1);  // backref.go:66, masked to 21 bits by res_pack
@@ -468,7 +529,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
         LL = ld > lu ? ld : lu;
         if (LL > 0) pL = (lu > ld) ? pupL : ((ablate & 2) ? SA[kdnL] : leftmost_long(S, kdnL, LL, wsL, i));
     }
-    res[sg.off + i] = select_backref(D, T, i, maxLen, minD, dynOK && !(ablate & 1), Ls, ps, LL, pL);
+    res[sg.off + i] = select_backref(D, T, i, maxLen, minD, dynOK && !(ablate & 1), Ls, ps, LL, pL, ablate);
 }
 
 // positions i < HEAD: brute force over the window [0, i) (identical for both window sizes there)
