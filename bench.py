@@ -22,6 +22,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(stage, n_blobs):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this same command, KB -> bytes).  FETCH_SIZE is left uncorrected:
+    the guide's x2 applies to wide coalesced streams only and these kernels mix 2/4/8/16-byte accesses."""
+    path = os.path.join(ROOT, "profiles", "r01_b_pmc_hbm_traffic.csv")
+    kernel = {"sa_build": "lzss::sa_build_kernel", "match": "lzss::match_kernel", "lcp": "lzss::lcp_kernel"}.get(stage)
+    if kernel is None or not os.path.exists(path) or n_blobs != 1250:
+        return None, None
+    total = 0.0
+    for line in open(path).read().splitlines()[1:]:
+        k, _, v, nd = line.rsplit(",", 3)
+        if k == kernel:
+            total += float(v) * 1024.0 / max(1, int(nd))
+    return int(total), "profiles/r01_b_pmc_hbm_traffic.csv (rocprofv3 --pmc, FETCH_SIZE + WRITE_SIZE, per launch)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +123,7 @@ def main():
         # algorithmic bytes of one launch: sum(n_in + n_out) + n_dict
         alg_bytes = in_bytes + int(out_total) + len(compress_amd.AugmentDict(dict_))
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom, len(blobs))
         line = {
             "metric": "compress MB/s (whole node, bit-exact) + % HBM roofline at 1/2/4/8 GPUs",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -116,7 +133,7 @@ def main():
                                    "blob b -> GPU b mod N", "blobs_per_gpu": len(blobs), "blob_bytes": args.blob_size,
                        "dict_bytes": len(dict_), "ratio": round(in_bytes / max(1, int(out_total)), 3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stages[dom], 3)},
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "decompress": {"value": round(in_bytes * world * args.steps / dec_elapsed / 1e6, 2), "unit": "MB/s (decompressed bytes)",

@@ -79,8 +79,9 @@ struct PinBuf {
 static inline uint64_t seg_stride(uint64_t n) { return (n + SEG_PAD + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN; }
 
 // ---- objects ----------------------------------------------------------------------------------------
-enum { ST_SA = 0, ST_LCP, ST_MATCH, ST_DECIDE, ST_WALK, ST_EMIT, ST_DECOMP, ST_COUNT };
-static const char *const kStageNames[ST_COUNT] = {"sa_build", "lcp", "match", "decide", "walk", "emit", "decompress"};
+enum { ST_SA = 0, ST_LCP, ST_WINDEX, ST_MHEAD, ST_MATCH, ST_DECIDE, ST_WALK, ST_EMIT, ST_DECOMP, ST_COUNT };
+static const char *const kStageNames[ST_COUNT] = {"sa_build", "lcp", "window_index", "match_head", "match",
+                                                  "decide", "walk", "emit", "decompress"};
 
 struct mi355_lzss_ctx {
     int device = 0;
@@ -278,7 +279,10 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
     launch_sa_build(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
     if ((rc = mark(b, ST_LCP)) != 0) return rc;
     launch_lcp(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
+    if ((rc = mark(b, ST_WINDEX)) != 0) return rc;
     launch_window_index(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
+    if ((rc = mark(b, ST_MHEAD)) != 0) return rc;
+    launch_match_head(d_segs, b->n_blobs, b->max_n, batch_index(b), b->ctx->view, b->res.as<uint32_t>(), sm);
     if ((rc = mark(b, ST_MATCH)) != 0) return rc;
     launch_match(d_segs, b->n_blobs, b->max_n, batch_index(b), b->ctx->view, b->res.as<uint32_t>(), skip_unqueried, sm);
     if ((rc = mark(b, ST_DECIDE)) != 0) return rc;

@@ -561,17 +561,20 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
     res[sg.off + i] = select_backref(D, T, i, maxLen, minD, dynOK, Ls, ps, LL, pL);
 }
 
-void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
-                  uint32_t *d_res, bool skip_unqueried, hipStream_t stream) {
+void launch_match_head(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
+                       uint32_t *d_res, hipStream_t stream) {
     if (n_segs == 0 || max_n == 0) return;
     const uint32_t head = max_n < (uint32_t)HEAD ? max_n : (uint32_t)HEAD;
     dim3 gh((head + 63) / 64, n_segs);
     hipLaunchKernelGGL(match_head_kernel, gh, dim3(64), 0, stream, d_segs, ix, dict, d_res);
-    if (max_n > (uint32_t)HEAD) {
-        dim3 g((max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS, n_segs);
-        static const int ablate = getenv("MI355_LZSS_ABLATE") ? atoi(getenv("MI355_LZSS_ABLATE")) : 0;  // timing experiments only
-        hipLaunchKernelGGL(match_kernel, g, dim3(MATCH_THREADS), 0, stream, d_segs, ix, dict, d_res, skip_unqueried ? 1 : 0, ablate);
-    }
+}
+
+void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
+                  uint32_t *d_res, bool skip_unqueried, hipStream_t stream) {
+    if (n_segs == 0 || max_n <= (uint32_t)HEAD) return;
+    static const int ablate = getenv("MI355_LZSS_ABLATE") ? atoi(getenv("MI355_LZSS_ABLATE")) : 0;  // timing experiments only
+    dim3 g((max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS, n_segs);
+    hipLaunchKernelGGL(match_kernel, g, dim3(MATCH_THREADS), 0, stream, d_segs, ix, dict, d_res, skip_unqueried ? 1 : 0, ablate);
 }
 
 }  // namespace lzss
