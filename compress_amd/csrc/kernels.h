@@ -6,7 +6,8 @@ namespace lzss {
 
 // ---- sa_build.hip -----------------------------------------------------------------------------
 struct SaWork {       // batch-wide arrays, indexed [seg.off + k], k in [0, n]
-    int32_t *keyA, *valA, *keyB, *valB;  // radix-sort ping-pong (rank key, suffix)
+    uint64_t *recA, *recB;               // sort ping-pong of the main kernel (8-byte records, [seg.off + k])
+    int32_t *keyA, *valA, *keyB, *valB;  // the same memory as int32 arrays (fallback kernel: rank key, suffix)
     int32_t *rkA, *rkB;                  // group ranks, double buffered
     uint8_t *flags;                      // group-boundary flags
     int32_t *sa, *isa;                   // outputs

@@ -312,51 +312,261 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_full_kernel(const Seg *se
 }
 
 
-// ---- main kernel: rounds touch only the suffixes that still share their group ----------------------------
-// A bitmap in LDS (one bit per suffix) marks the suffixes whose group has more than one member.  Per round:
-//   A  one coalesced sweep over the current order keeps the marked members of the induction sequence
-//      (p = SA[j] - h) in wave-private compact lists;
-//   B  the lists are concatenated into a dense array with their rank keys (one gather per ACTIVE suffix);
-//   C  the same stable LSD radix passes as the fallback, over the dense array only;
-//   D  boundaries of (old group, second key) give every active suffix its new group start and its slot in
-//      the suffix array (old group start + index inside the group); suffixes now alone leave the bitmap.
-// Suffixes that are alone in their group never move again, so SA and the ranks are updated in place.
+// ---- main kernel --------------------------------------------------------------------------------------
+// Rounds touch only the suffixes that still share their group, and every sort pass is a WORKGROUP-wide
+// stable scatter over tiles of SA_TILE sequence entries (the 16 waves rank their 64-entry steps against
+// wave-private LDS counters, one scan per tile turns them into offsets behind running per-bin bases), so a
+// pass keeps one output stream per bin and needs no counting sweep: the bin totals are known beforehand.
+//
+//   initial order: SA_INIT_SYMS LSD passes whose digit is read from the text (only the suffix numbers move);
+//                  the bin totals of every pass follow from one byte histogram of the text
+//   regroup (D):   boundaries of (group, second key) in the sorted records give every active suffix its slot
+//                  in the suffix array and its new group start; suffixes now alone leave the `act` bitmap;
+//                  the digits of the new group starts are counted for the next round's two passes
+//   S1:            one sweep over the suffix array: the active members of the induction sequence
+//                  p = SA[j] - h, with their group start k1 = RK[p] (the one gather of a round) and the group
+//                  start k2 of slot j (from the `gb` bitmap), packed into 8-byte records and scattered by the
+//                  low digit of k1
+//   S2:            scatter of the records by the high digit of k1 -> sorted by (k1, sequence order)
+// Suffixes alone in their group never move again, so SA and the ranks are updated in place.
 constexpr uint32_t SA_BITMAP_MAX_N = 300000;
 constexpr int SA_INIT_SYMS = 4;  // depth of the initial sort (symbols compared straight from the text)
+constexpr int SA_K = 4;          // sequence entries per thread and tile
+constexpr int SA_WSPAN = 64 * SA_K;            // consecutive entries of one wave inside a tile
+constexpr int SA_TILE = SA_THREADS * SA_K;
 
-// the first SA_INIT_SYMS symbols of suffix p as two integers (high half, low half), sentinel-aware
-__device__ inline void init_keys(const uint8_t *T, uint32_t n, uint32_t p, int &k1, int &k2) {
-    uint32_t s[SA_INIT_SYMS];
+// the first SA_INIT_SYMS symbols of suffix p (0 = sentinel, byte + 1 otherwise), 9 bits each
+__device__ inline uint64_t init_key(const uint8_t *T, uint32_t n, uint32_t p) {
+    uint64_t k = 0;
 #pragma unroll
-    for (int t = 0; t < SA_INIT_SYMS; ++t) s[t] = (p + t < n) ? (uint32_t)T[p + t] + 1u : 0u;
-    uint32_t hi = 0, lo = 0;
-#pragma unroll
-    for (int t = 0; t < SA_INIT_SYMS / 2; ++t) hi = (hi << 9) | s[t];
-#pragma unroll
-    for (int t = SA_INIT_SYMS / 2; t < SA_INIT_SYMS; ++t) lo = (lo << 9) | s[t];
-    k1 = (int)hi;
-    k2 = (int)lo;
-}  // bitmap words live in dynamic LDS
+    for (int t = 0; t < SA_INIT_SYMS; ++t) k = (k << 9) | ((p + t < n) ? (uint64_t)T[p + t] + 1u : 0u);
+    return k;
+}
 
-struct SaShared2 {
-    SaShared s;
-    int32_t wbase[SA_WAVES + 1];
-    int32_t wlastS[SA_WAVES];
+template <int DB>
+__device__ inline uint64_t match_bits(int d, uint64_t amask) {
+    uint64_t peers = amask;
+#pragma unroll
+    for (int bit = 0; bit < DB; ++bit) {
+        const bool b = (d >> bit) & 1;
+        const uint64_t bal = __ballot(b);
+        peers &= b ? bal : ~bal;
+    }
+    return peers;
+}
+
+template <int DB>
+struct SaLds {
+    static constexpr int NB = 1 << DB;
+    uint16_t *whist;   // [SA_WAVES][NB] entries of the current tile per wave and bin (zero between tiles)
+    uint16_t *woff;    // [SA_WAVES][NB] tile-local offset of wave w's entries inside bin b
+    int32_t *tstart;   // [NB] output index of the tile's first entry of bin b
+    int32_t *base;     // [NB] running output index of bin b
+    int32_t *hl, *hh;  // [NB] digit counts of the next round's keys (low / high digit)
+    uint32_t *act;     // bit p: suffix p still shares its group
+    uint32_t *gb;      // bit j: slot j of the suffix array starts a group
+    __device__ SaLds(uint32_t *mem, uint32_t words) {
+        act = mem;
+        gb = act + words;
+        tstart = (int32_t *)(gb + words);
+        base = tstart + NB;
+        hl = base + NB;
+        hh = hl + NB;
+        whist = (uint16_t *)(hh + NB);
+        woff = whist + SA_WAVES * NB;
+    }
+    static size_t bytes(uint32_t words) { return (size_t)words * 8 + (size_t)NB * 16 + (size_t)SA_WAVES * NB * 4; }
 };
 
+struct SaCarry {
+    int32_t a[2][SA_WAVES];
+    int32_t b[2][SA_WAVES];
+    int32_t wcount[SA_WAVES];
+};
+
+// rank of this lane's entry among the entries of its wave's tile part with the same digit (stable)
+template <int DB>
+__device__ inline int tile_rank(uint16_t *wrow, int d, bool valid, int lane) {
+    const uint64_t amask = __ballot(valid);
+    const uint64_t peers = match_bits<DB>(d, amask);
+    const int cnt = __popcll(peers);
+    const int rank = __popcll(peers & lanemask_lt(lane));
+    const int lh = valid ? (int)wrow[d] : 0;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == cnt - 1) wrow[d] = (uint16_t)(lh + cnt);
+    __builtin_amdgcn_wave_barrier();
+    return lh + rank;
+}
+
+// per-wave tile counts -> offsets; advances the running bases (call between two barriers)
+template <int DB>
+__device__ inline void tile_offsets(const SaLds<DB> &L, int tid) {
+    constexpr int NB = 1 << DB;
+    for (int b = tid; b < NB; b += SA_THREADS) {
+        int run = 0;
+#pragma unroll
+        for (int ww = 0; ww < SA_WAVES; ++ww) {
+            const int t = L.whist[ww * NB + b];
+            L.whist[ww * NB + b] = 0;
+            L.woff[ww * NB + b] = (uint16_t)run;
+            run += t;
+        }
+        const int s = L.base[b];
+        L.tstart[b] = s;
+        L.base[b] = s + run;
+    }
+}
+
+// base[b] = sum of src[0..b) (ends with a barrier; src must be complete and visible: barrier before)
+__device__ inline void bins_scan(const int32_t *src, int32_t *base, int nb, int tid) {
+    if (tid < 64) {
+        int carry = 0;
+        for (int b0 = 0; b0 < nb; b0 += 64) {
+            const int v = src[b0 + tid];
+            const int inc = wave_incl_add(v, tid);
+            base[b0 + tid] = carry + inc - v;
+            carry += __shfl(inc, 63);
+        }
+    }
+    __syncthreads();
+}
+
+// Regroup: `m` sorted entries (INITIAL: suffixes in vcur, ordered by their first SA_INIT_SYMS symbols;
+// otherwise records sorted by (k1, sequence order)) -> slots, new group starts, bitmaps, next digit counts.
+// Returns the number of suffixes that still share their group.
+template <bool INITIAL, int DB>
+__device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uint8_t *T, uint32_t n, const int32_t *vcur,
+                                      const uint64_t *rec, uint32_t m, int32_t *sa, int32_t *rk, int tid) {
+    constexpr int NB = 1 << DB;
+    const int lane = tid & 63, w = tid >> 6;
+    int tileK = -1, tileS = -1;
+    uint32_t rem = 0;
+    int par = 0;
+    for (uint32_t t0 = 0; t0 < m; t0 += SA_TILE, par ^= 1) {
+        const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
+        uint64_t key[SA_K];
+        int p[SA_K];
+#pragma unroll
+        for (int s = 0; s < SA_K; ++s) {
+            const uint32_t u = wb + s * 64 + lane;
+            key[s] = 0;
+            p[s] = 0;
+            if (u < m) {
+                if (INITIAL) {
+                    p[s] = vcur[u];
+                    key[s] = init_key(T, n, (uint32_t)p[s]);
+                } else {
+                    const uint64_t r = rec[u];
+                    p[s] = (int)(r & 0xFFFFFu);
+                    key[s] = r >> 20;
+                }
+            }
+        }
+        // neighbours across the wave's span (uniform loads)
+        uint64_t pkey = 0, nkey = 0;
+        const uint32_t un = wb + SA_WSPAN;
+        if (wb > 0 && wb < m) pkey = INITIAL ? init_key(T, n, (uint32_t)vcur[wb - 1]) : (rec[wb - 1] >> 20);
+        if (un < m) nkey = INITIAL ? init_key(T, n, (uint32_t)vcur[un]) : (rec[un] >> 20);
+
+        int fK[SA_K], fS[SA_K];
+#pragma unroll
+        for (int s = 0; s < SA_K; ++s) {
+            const uint32_t u = wb + s * 64 + lane;
+            uint64_t q = __shfl_up(key[s], 1);
+            const uint64_t q63 = __shfl(key[s > 0 ? s - 1 : 0], 63);  // executed by all lanes
+            if (lane == 0) q = (s == 0) ? pkey : q63;
+            const bool valid = u < m;
+            const bool first = (u == 0);
+            fS[s] = valid && (first || key[s] != q);
+            fK[s] = valid && (first || (!INITIAL && (key[s] >> 20) != (q >> 20)));
+        }
+        int single[SA_K];
+        int gKl[SA_K], gSl[SA_K];
+        int runK = -1, runS = -1;
+#pragma unroll
+        for (int s = 0; s < SA_K; ++s) {
+            const uint32_t u = wb + s * 64 + lane;
+            int nf = __shfl_down(fS[s], 1);
+            const int nf0 = (s + 1 < SA_K) ? __shfl(fS[s + 1 < SA_K ? s + 1 : s], 0) : 0;
+            if (lane == 63) nf = (s + 1 < SA_K) ? nf0 : ((un < m) ? (int)(nkey != key[s]) : 1);
+            if (u + 1 >= m) nf = 1;
+            single[s] = fS[s] && nf;
+            int gK = wave_incl_max(fK[s] ? (int)u : -1, lane);
+            int gS = wave_incl_max(fS[s] ? (int)u : -1, lane);
+            gK = max(gK, runK);
+            gS = max(gS, runS);
+            runK = __shfl(gK, 63);
+            runS = __shfl(gS, 63);
+            gKl[s] = gK;
+            gSl[s] = gS;
+        }
+        if (lane == 0) {
+            cy.a[par][w] = runK;
+            cy.b[par][w] = runS;
+        }
+        __syncthreads();
+        int cinK = tileK, cinS = tileS;
+        for (int ww = 0; ww < SA_WAVES; ++ww) {
+            const int a = cy.a[par][ww], b = cy.b[par][ww];
+            if (ww < w) {
+                cinK = max(cinK, a);
+                cinS = max(cinS, b);
+            }
+            tileK = max(tileK, a);
+            tileS = max(tileS, b);
+        }
+#pragma unroll
+        for (int s = 0; s < SA_K; ++s) {
+            const uint32_t u = wb + s * 64 + lane;
+            const bool valid = u < m;
+            const int gK = max(gKl[s], cinK), gS = max(gSl[s], cinS);
+            const int k1 = INITIAL ? 0 : (int)(key[s] >> 20);
+            const int slot = k1 + ((int)u - gK);
+            const int nr = k1 + (gS - gK);
+            const bool sgl = single[s];
+            if (valid) {
+                sa[slot] = p[s];
+                rk[p[s]] = nr;
+                if (INITIAL) {
+                    if (!sgl) atomicOr(&L.act[(uint32_t)p[s] >> 5], 1u << (p[s] & 31));
+                } else if (sgl) {
+                    atomicAnd(&L.act[(uint32_t)p[s] >> 5], ~(1u << (p[s] & 31)));
+                }
+                if (fS[s] && (INITIAL || !fK[s])) atomicOr(&L.gb[(uint32_t)slot >> 5], 1u << (slot & 31));
+            }
+            // digit counts of the keys of the next round, one update per run of equal group starts
+            const uint64_t vmask = __ballot(valid);
+            const bool head = valid && (fS[s] || lane == 0);
+            const uint64_t heads = __ballot(head);
+            if (head && !sgl) {
+                const uint64_t rest = (lane == 63) ? 0ull : (heads >> (lane + 1));
+                const int nxt = rest ? lane + 1 + (int)__builtin_ctzll(rest) : __popcll(vmask);
+                const int len = nxt - lane;
+                atomicAdd(&L.hl[nr & (NB - 1)], len);
+                atomicAdd(&L.hh[nr >> DB], len);
+            }
+            rem += (uint32_t)__popcll(__ballot(valid && !sgl));
+        }
+    }
+    if (lane == 0) cy.wcount[w] = (int)rem;
+    __syncthreads();
+    uint32_t total = 0;
+    for (int ww = 0; ww < SA_WAVES; ++ww) total += (uint32_t)cy.wcount[ww];
+    __syncthreads();
+    return total;
+}
+
+template <int DB>
 __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
-    __shared__ SaShared2 sh2;
-    extern __shared__ uint32_t bits[];
-    SaShared &sh = sh2.s;
+    constexpr int NB = 1 << DB;
+    constexpr int MASK = NB - 1;
+    __shared__ SaCarry cy;
+    extern __shared__ uint32_t dyn_lds[];
     const Seg sg = segs[blockIdx.x];
     const uint8_t *T = text + sg.off;
     const uint32_t n = sg.n;
     const uint32_t N = n + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-
-    int32_t *keyA = wk.keyA + sg.off, *valA = wk.valA + sg.off;
-    int32_t *keyB = wk.keyB + sg.off, *valB = wk.valB + sg.off;
-    uint8_t *flags = wk.flags + sg.off;
     int32_t *sa = wk.sa + sg.off, *rk = wk.isa + sg.off;
 
     if (N == 1) {
@@ -366,229 +576,175 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
         }
         return;
     }
-    const uint32_t C = (((N + SA_WAVES - 1) / SA_WAVES) + 63u) & ~63u;
-    const uint32_t cbeg = min((uint32_t)w * C, N), cend = min(cbeg + C, N);
-    const int KB = 32 - __clz((int)(N - 1));
-    const int P = (KB + SA_MAXDB - 1) / SA_MAXDB;
-    const int DB = (KB + P - 1) / P;
-    const int mask = (1 << DB) - 1;
+    const uint32_t words = ((N + 63) / 64) * 2;  // bitmap words, whole 64-bit groups
+    const SaLds<DB> L(dyn_lds, words);
+    uint64_t *recA = wk.recA + sg.off, *recB = wk.recB + sg.off;
+    int32_t *vA = (int32_t *)recA, *vB = (int32_t *)recB;
 
-    for (uint32_t x = tid; x < (N + 31) / 32; x += SA_THREADS) bits[x] = 0;
+    for (uint32_t x = tid; x < 2 * words; x += SA_THREADS) L.act[x] = 0;  // act and gb
+    for (int x = tid; x < 4 * NB; x += SA_THREADS) L.tstart[x] = 0;       // tstart, base, hl, hh
+    for (int x = tid; x < SA_WAVES * NB; x += SA_THREADS) L.whist[x] = 0;
+    __syncthreads();
 
-    // ---- initial order by the first SA_INIT_SYMS symbols (0 = sentinel, byte + 1 otherwise): LSD passes
-    //      whose digit is read from the text, so only the suffix numbers move (4 bytes per element)
+    // ---- byte histogram of the text (hl[c] = occurrences of byte c)
+    for (uint32_t q0 = (uint32_t)w * 64; q0 < n; q0 += SA_THREADS) {
+        const uint32_t q = q0 + lane;
+        const bool valid = q < n;
+        const int c = valid ? (int)T[q] : 0;
+        const uint64_t peers = match_bits<8>(c, __ballot(valid));
+        if (valid && (peers & lanemask_lt(lane)) == 0) atomicAdd(&L.hl[c], __popcll(peers));
+    }
+    __syncthreads();
+
+    // ---- initial order by the first SA_INIT_SYMS symbols: LSD passes, digit read from the text
     {
         const int32_t *vin = nullptr;  // pass 0 reads the identity
-        int32_t *vout = valA;
+        int32_t *vout = vA;
         for (int pass = 0; pass < SA_INIT_SYMS; ++pass) {
             const uint32_t d = (uint32_t)(SA_INIT_SYMS - 1 - pass);  // symbol index used by this pass
-            int32_t *hrow = sh.hist[w];
-            hist_clear(sh, tid);
-            __syncthreads();
-            for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                const bool active = j < cend;
-                int key = 0;
-                if (active) {
-                    const uint32_t q = (vin ? (uint32_t)vin[j] : j) + d;
-                    key = q < n ? (int)T[q] + 1 : 0;
+            // bin totals: the symbols at p + d for p in [0, N) are the text without its first d bytes, then
+            // min(d, n) + 1 sentinels
+            const uint32_t dd = min(d, n);
+            if (tid < NB) {
+                int v = 0;
+                if (tid == 0) {
+                    v = (int)dd + 1;
+                } else if (tid <= 256) {
+                    v = L.hl[tid - 1];
+                    for (uint32_t q = 0; q < dd; ++q) v -= ((int)T[q] + 1 == tid) ? 1 : 0;
                 }
-                hist_add(hrow, key, active, lane);
+                L.hh[tid] = v;
             }
-            hist_scan(sh, tid, SA_BINS);
-            for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                const bool active = j < cend;
-                int key = 0, val = 0;
-                if (active) {
-                    val = vin ? vin[j] : (int)j;
-                    const uint32_t q = (uint32_t)val + d;
-                    key = q < n ? (int)T[q] + 1 : 0;
+            __syncthreads();
+            bins_scan(L.hh, L.base, NB, tid);
+            for (uint32_t t0 = 0; t0 < N; t0 += SA_TILE) {
+                const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
+                int val[SA_K], sym[SA_K], loc[SA_K];
+#pragma unroll
+                for (int s = 0; s < SA_K; ++s) {
+                    const uint32_t e = wb + s * 64 + lane;
+                    val[s] = (e < N) ? (vin ? vin[e] : (int)e) : 0;
                 }
-                const uint64_t amask = __ballot(active);
-                const uint64_t peers = match_digit(key, amask);
-                const int cnt = __popcll(peers);
-                const int rank = __popcll(peers & lanemask_lt(lane));
-                const int base = hrow[key];
-                if (active) vout[base + rank] = val;
-                __builtin_amdgcn_wave_barrier();
-                if (active && rank == cnt - 1) hrow[key] = base + cnt;
-                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int s = 0; s < SA_K; ++s) {
+                    const uint32_t e = wb + s * 64 + lane;
+                    const uint32_t q = (uint32_t)val[s] + d;
+                    sym[s] = (e < N && q < n) ? (int)T[q] + 1 : 0;
+                }
+#pragma unroll
+                for (int s = 0; s < SA_K; ++s) {
+                    const uint32_t e = wb + s * 64 + lane;
+                    loc[s] = tile_rank<9>(L.whist + w * NB, sym[s], e < N, lane);
+                }
+                __syncthreads();
+                tile_offsets<DB>(L, tid);
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < SA_K; ++s) {
+                    const uint32_t e = wb + s * 64 + lane;
+                    if (e < N) vout[L.tstart[sym[s]] + (int)L.woff[w * NB + sym[s]] + loc[s]] = val[s];
+                }
             }
             __syncthreads();
             vin = vout;
-            vout = (vout == valA) ? valB : valA;
+            vout = (vout == vA) ? vB : vA;
         }
     }
-    const int32_t *kcur = keyB, *vcur = (SA_INIT_SYMS & 1) ? valA : valB;
-    uint32_t m = N;                            // its length
-    uint32_t dbeg = cbeg, dend = cend;         // this wave's chunk of it
-    uint32_t h = 0;
-    bool initial = true;
-    for (;;) {
-        // ---- D: boundaries, new group starts, slots
-        {
-            int lastK = -1, lastS = -1;
-            int c1 = 0, c2 = 0;
-            for (uint32_t u0 = dbeg; u0 < dend; u0 += 64) {
-                const uint32_t u = u0 + lane;
-                const bool act = u < dend;
-                int p = 0, k1 = -2, k2 = -1;
-                if (act) {
-                    p = vcur[u];
-                    if (initial) {
-                        init_keys(T, n, (uint32_t)p, k1, k2);
-                    } else {
-                        k1 = kcur[u];
-                        if ((uint32_t)p + h < N) k2 = rk[(uint32_t)p + h];
-                    }
-                }
-                int q1 = __shfl_up(k1, 1), q2 = __shfl_up(k2, 1);
-                if (lane == 0) {
-                    if (u0 == dbeg) {
-                        if (u > 0) {
-                            const int pp = vcur[u - 1];
-                            if (initial) {
-                                init_keys(T, n, (uint32_t)pp, q1, q2);
-                            } else {
-                                q1 = kcur[u - 1];
-                                q2 = ((uint32_t)pp + h < N) ? rk[(uint32_t)pp + h] : -1;
-                            }
-                        } else {
-                            q1 = -3;
-                        }
-                    } else {
-                        q1 = c1;
-                        q2 = c2;
-                    }
-                }
-                const bool fK = act && k1 != q1;
-                const bool fS = act && (fK || k2 != q2);
-                c1 = __shfl(k1, 63);
-                c2 = __shfl(k2, 63);
-                if (act) flags[u] = (uint8_t)((fK ? 1 : 0) | (fS ? 2 : 0));
-                const uint64_t bK = __ballot(fK), bS = __ballot(fS);
-                if (bK) lastK = (int)u0 + 63 - __clzll(bK);
-                if (bS) lastS = (int)u0 + 63 - __clzll(bS);
-            }
-            if (lane == 0) {
-                sh.wlast[w] = lastK;
-                sh2.wlastS[w] = lastS;
-            }
-            __syncthreads();
-            int carryK = -1, carryS = -1;
-            for (int ww = 0; ww < w; ++ww) {
-                carryK = max(carryK, sh.wlast[ww]);
-                carryS = max(carryS, sh2.wlastS[ww]);
-            }
-            int rem = 0;
-            for (uint32_t u0 = dbeg; u0 < dend; u0 += 64) {
-                const uint32_t u = u0 + lane;
-                const bool act = u < dend;
-                int f = 0, fn = 2, p = 0, k1 = 0;
-                if (act) {
-                    f = flags[u];
-                    if (u + 1 < m) fn = flags[u + 1];
-                    p = vcur[u];
-                    if (!initial) k1 = kcur[u];
-                }
-                int gK = wave_incl_max((f & 1) ? (int)u : -1, lane);
-                int gS = wave_incl_max((f & 2) ? (int)u : -1, lane);
-                gK = max(gK, carryK);
-                gS = max(gS, carryS);
-                carryK = __shfl(gK, 63);
-                carryS = __shfl(gS, 63);
-                const bool single = (f & 2) && (fn & 2);
-                if (act) {
-                    const int slot = initial ? (int)u : k1 + ((int)u - gK);
-                    const int nr = initial ? gS : k1 + (gS - gK);
-                    sa[slot] = p;
-                    rk[p] = nr;
-                    if (initial) {
-                        if (!single) atomicOr(&bits[(uint32_t)p >> 5], 1u << (p & 31));
-                    } else if (single) {
-                        atomicAnd(&bits[(uint32_t)p >> 5], ~(1u << (p & 31)));
-                    }
-                }
-                rem += __popcll(__ballot(act && !single));
-            }
-            if (lane == 0) sh.wcount[w] = rem;
-            __syncthreads();
-            int remaining = 0;
-            for (int ww = 0; ww < SA_WAVES; ++ww) remaining += sh.wcount[ww];
-            if (remaining == 0 || h >= N || --max_rounds < 0) break;
-        }
-        initial = false;
-        h = (h == 0) ? (uint32_t)SA_INIT_SYMS : h * 2;
+    const int32_t *vcur = (SA_INIT_SYMS & 1) ? vA : vB;
+    for (int x = tid; x < 2 * NB; x += SA_THREADS) L.hl[x] = 0;  // hl, hh
+    __syncthreads();
 
-        // ---- A: the marked members of the sequence p = SA[j] - h, compacted per wave into valB[cbeg..]
+    uint32_t m = sa_regroup<true, DB>(L, cy, T, n, vcur, nullptr, N, sa, rk, tid);
+    uint32_t h = (uint32_t)SA_INIT_SYMS;
+    while (m != 0 && h < N && --max_rounds >= 0) {
+        // ---- S1: active members of the sequence p = SA[j] - h -> records, scattered by the low digit of k1
+        bins_scan(L.hl, L.base, NB, tid);
         {
-            uint32_t wrun = 0;
-            for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                bool a = false;
-                uint32_t p = 0;
-                if (j < cend) {
-                    const uint32_t s = (uint32_t)sa[j];
-                    p = s >= h ? s - h : N - h + s;
-                    a = (bits[p >> 5] >> (p & 31)) & 1u;
-                }
-                const uint64_t bal = __ballot(a);
-                if (a) valB[cbeg + wrun + (uint32_t)__popcll(bal & lanemask_lt(lane))] = (int)p;
-                wrun += (uint32_t)__popcll(bal);
-            }
-            if (lane == 0) sh.wcount[w] = (int)wrun;
-            __syncthreads();
-            if (tid == 0) {
-                int acc = 0;
-                for (int ww = 0; ww < SA_WAVES; ++ww) {
-                    sh2.wbase[ww] = acc;
-                    acc += sh.wcount[ww];
-                }
-                sh2.wbase[SA_WAVES] = acc;
-            }
-            hist_clear(sh, tid);
-            __syncthreads();
-            m = (uint32_t)sh2.wbase[SA_WAVES];
-        }
-        const uint32_t Cm = (((m + SA_WAVES - 1) / SA_WAVES) + 63u) & ~63u;
-        dbeg = min((uint32_t)w * Cm, m);
-        dend = min(dbeg + Cm, m);
-
-        // ---- B: dense (rank key, suffix) array in (keyA, valA), fused with the count of digit 0
-        for (uint32_t u0 = dbeg; u0 < dend; u0 += 64) {
-            const uint32_t u = u0 + lane;
-            const bool act = u < dend;
-            int key = 0;
-            if (act) {
-                int sw = 0;  // source wave: wbase[sw] <= u < wbase[sw + 1]
+            int tileG = 0;  // slot 0 always starts a group
+            int par = 0;
+            for (uint32_t t0 = 0; t0 < N; t0 += SA_TILE, par ^= 1) {
+                const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
+                int sv[SA_K];
 #pragma unroll
-                for (int ww = 1; ww < SA_WAVES; ++ww) sw += ((uint32_t)sh2.wbase[ww] <= u) ? 1 : 0;
-                const uint32_t sbeg = min((uint32_t)sw * C, N);
-                const int p = valB[sbeg + (u - (uint32_t)sh2.wbase[sw])];
-                key = rk[p];
-                keyA[u] = key;
-                valA[u] = p;
-            }
-            hist_add(sh.hist[w], key & mask, act, lane);
-        }
-        // ---- C: P stable passes over the dense array
-        int32_t *kin = keyA, *vin = valA, *kout = keyB, *vout = valB;
-        for (int pass = 0; pass < P; ++pass) {
-            if (pass > 0) {
-                hist_clear(sh, tid);
+                for (int s = 0; s < SA_K; ++s) {
+                    const uint32_t j = wb + s * 64 + lane;
+                    sv[s] = (j < N) ? sa[j] : 0;
+                }
+                int p[SA_K], k1[SA_K], k2[SA_K], loc[SA_K];
+                bool a[SA_K];
+#pragma unroll
+                for (int s = 0; s < SA_K; ++s) {
+                    const uint32_t j = wb + s * 64 + lane;
+                    const uint32_t sx = (uint32_t)sv[s];
+                    const uint32_t pp = sx >= h ? sx - h : N - h + sx;
+                    p[s] = (int)pp;
+                    a[s] = (j < N) && ((L.act[pp >> 5] >> (pp & 31)) & 1u);
+                    k1[s] = a[s] ? rk[pp] : 0;
+                }
+                int runG = -1;
+#pragma unroll
+                for (int s = 0; s < SA_K; ++s) {
+                    const uint32_t j0 = wb + s * 64;
+                    uint64_t gw = 0;
+                    if (j0 < N) gw = (uint64_t)L.gb[j0 >> 5] | ((uint64_t)L.gb[(j0 >> 5) + 1] << 32);
+                    const uint64_t le = gw & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+                    k2[s] = le ? (int)j0 + 63 - (int)__builtin_clzll(le) : runG;
+                    if (gw) runG = (int)j0 + 63 - (int)__builtin_clzll(gw);
+                    loc[s] = tile_rank<DB>(L.whist + w * NB, k1[s] & MASK, a[s], lane);
+                }
+                if (lane == 0) cy.a[par][w] = runG;
                 __syncthreads();
-                count_chunk(sh, kin, dbeg, dend, pass * DB, mask, w, lane);
+                tile_offsets<DB>(L, tid);
+                int cin = tileG;
+                for (int ww = 0; ww < SA_WAVES; ++ww) {
+                    const int g = cy.a[par][ww];
+                    if (ww < w) cin = max(cin, g);
+                    tileG = max(tileG, g);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < SA_K; ++s) {
+                    if (a[s]) {
+                        const int d = k1[s] & MASK;
+                        const int g = k2[s] < 0 ? cin : k2[s];
+                        recA[L.tstart[d] + (int)L.woff[w * NB + d] + loc[s]] =
+                            ((uint64_t)(uint32_t)k1[s] << 40) | ((uint64_t)(uint32_t)g << 20) | (uint64_t)(uint32_t)p[s];
+                    }
+                }
             }
-            hist_scan(sh, tid, 1 << DB);
-            scatter_chunk(sh, kin, vin, kout, vout, dbeg, dend, pass * DB, mask, w, lane);
-            __syncthreads();
-            int32_t *t;
-            t = kin; kin = kout; kout = t;
-            t = vin; vin = vout; vout = t;
         }
-        kcur = kin;
-        vcur = vin;
+        __syncthreads();
+        // ---- S2: records by the high digit of k1
+        bins_scan(L.hh, L.base, NB, tid);
+        for (int x = tid; x < 2 * NB; x += SA_THREADS) L.hl[x] = 0;  // hl, hh: refilled by the regroup below
+        for (uint32_t t0 = 0; t0 < m; t0 += SA_TILE) {
+            const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
+            uint64_t r[SA_K];
+            int loc[SA_K];
+#pragma unroll
+            for (int s = 0; s < SA_K; ++s) {
+                const uint32_t u = wb + s * 64 + lane;
+                r[s] = (u < m) ? recA[u] : 0;
+            }
+#pragma unroll
+            for (int s = 0; s < SA_K; ++s) {
+                const uint32_t u = wb + s * 64 + lane;
+                loc[s] = tile_rank<DB>(L.whist + w * NB, (int)(r[s] >> (40 + DB)), u < m, lane);
+            }
+            __syncthreads();
+            tile_offsets<DB>(L, tid);
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < SA_K; ++s) {
+                const uint32_t u = wb + s * 64 + lane;
+                const int d = (int)(r[s] >> (40 + DB));
+                if (u < m) recB[L.tstart[d] + (int)L.woff[w * NB + d] + loc[s]] = r[s];
+            }
+        }
+        __syncthreads();
+        // ---- D: new groups
+        m = sa_regroup<false, DB>(L, cy, T, n, nullptr, recB, m, sa, rk, tid);
+        h *= 2;
     }
 }
 
@@ -690,10 +846,24 @@ void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, con
 void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
                      hipStream_t stream) {
     if (n_segs == 0) return;
-    if (max_n + 1 <= SA_BITMAP_MAX_N) {
-        const size_t lds = ((size_t)max_n + 1 + 31) / 32 * 4;
-        static const int max_rounds = getenv("MI355_LZSS_SA_ROUNDS") ? atoi(getenv("MI355_LZSS_SA_ROUNDS")) : 1000;  // timing experiments only
-        hipLaunchKernelGGL(sa_build_kernel, dim3(n_segs), dim3(SA_THREADS), lds, stream, d_segs, d_text, wk, max_rounds);
+    static const int max_rounds = getenv("MI355_LZSS_SA_ROUNDS") ? atoi(getenv("MI355_LZSS_SA_ROUNDS")) : 1000;  // timing experiments only
+    const uint32_t N = max_n + 1;
+    const uint32_t words = ((N + 63) / 64) * 2;
+    static bool attr_set = false;  // both instantiations may use more than the default 64 KiB of dynamic LDS
+    if (!attr_set) {
+        const uint32_t wmax9 = (((1u << 18) + 63) / 64) * 2, wmax10 = ((SA_BITMAP_MAX_N + 63) / 64) * 2;
+        (void)hipFuncSetAttribute((const void *)sa_build_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)SaLds<9>::bytes(wmax9));
+        (void)hipFuncSetAttribute((const void *)sa_build_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)SaLds<10>::bytes(wmax10));
+        attr_set = true;
+    }
+    if (N <= (1u << 18)) {
+        hipLaunchKernelGGL(sa_build_kernel<9>, dim3(n_segs), dim3(SA_THREADS), SaLds<9>::bytes(words), stream, d_segs,
+                           d_text, wk, max_rounds);
+    } else if (N <= SA_BITMAP_MAX_N) {
+        hipLaunchKernelGGL(sa_build_kernel<10>, dim3(n_segs), dim3(SA_THREADS), SaLds<10>::bytes(words), stream, d_segs,
+                           d_text, wk, max_rounds);
     } else {
         hipLaunchKernelGGL(sa_build_full_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, d_text, wk);
     }
