@@ -331,9 +331,17 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_full_kernel(const Seg *se
 // Suffixes alone in their group never move again, so SA and the ranks are updated in place.
 constexpr uint32_t SA_BITMAP_MAX_N = 300000;
 constexpr int SA_INIT_SYMS = 4;  // depth of the initial sort (symbols compared straight from the text)
-constexpr int SA_K = 4;          // sequence entries per thread and tile
+#ifndef SA_MAIN_THREADS
+#define SA_MAIN_THREADS 512
+#endif
+#ifndef SA_MAIN_K
+#define SA_MAIN_K 8
+#endif
+constexpr int SAM_THREADS = SA_MAIN_THREADS;
+constexpr int SAM_WAVES = SAM_THREADS / 64;
+constexpr int SA_K = SA_MAIN_K;  // sequence entries per thread and tile
 constexpr int SA_WSPAN = 64 * SA_K;            // consecutive entries of one wave inside a tile
-constexpr int SA_TILE = SA_THREADS * SA_K;
+constexpr int SA_TILE = SAM_THREADS * SA_K;
 
 // the first SA_INIT_SYMS symbols of suffix p (0 = sentinel, byte + 1 otherwise), 9 bits each
 __device__ inline uint64_t init_key(const uint8_t *T, uint32_t n, uint32_t p) {
@@ -358,8 +366,8 @@ __device__ inline uint64_t match_bits(int d, uint64_t amask) {
 template <int DB>
 struct SaLds {
     static constexpr int NB = 1 << DB;
-    uint16_t *whist;   // [SA_WAVES][NB] entries of the current tile per wave and bin (zero between tiles)
-    uint16_t *woff;    // [SA_WAVES][NB] tile-local offset of wave w's entries inside bin b
+    uint16_t *whist;   // [SAM_WAVES][NB] entries of the current tile per wave and bin (zero between tiles)
+    uint16_t *woff;    // [SAM_WAVES][NB] tile-local offset of wave w's entries inside bin b
     int32_t *tstart;   // [NB] output index of the tile's first entry of bin b
     int32_t *base;     // [NB] running output index of bin b
     int32_t *hl, *hh;  // [NB] digit counts of the next round's keys (low / high digit)
@@ -373,15 +381,15 @@ struct SaLds {
         hl = base + NB;
         hh = hl + NB;
         whist = (uint16_t *)(hh + NB);
-        woff = whist + SA_WAVES * NB;
+        woff = whist + SAM_WAVES * NB;
     }
-    static size_t bytes(uint32_t words) { return (size_t)words * 8 + (size_t)NB * 16 + (size_t)SA_WAVES * NB * 4; }
+    static size_t bytes(uint32_t words) { return (size_t)words * 8 + (size_t)NB * 16 + (size_t)SAM_WAVES * NB * 4; }
 };
 
 struct SaCarry {
-    int32_t a[2][SA_WAVES];
-    int32_t b[2][SA_WAVES];
-    int32_t wcount[SA_WAVES];
+    int32_t a[2][SAM_WAVES];
+    int32_t b[2][SAM_WAVES];
+    int32_t wcount[SAM_WAVES];
 };
 
 // rank of this lane's entry among the entries of its wave's tile part with the same digit (stable)
@@ -402,10 +410,10 @@ __device__ inline int tile_rank(uint16_t *wrow, int d, bool valid, int lane) {
 template <int DB>
 __device__ inline void tile_offsets(const SaLds<DB> &L, int tid) {
     constexpr int NB = 1 << DB;
-    for (int b = tid; b < NB; b += SA_THREADS) {
+    for (int b = tid; b < NB; b += SAM_THREADS) {
         int run = 0;
 #pragma unroll
-        for (int ww = 0; ww < SA_WAVES; ++ww) {
+        for (int ww = 0; ww < SAM_WAVES; ++ww) {
             const int t = L.whist[ww * NB + b];
             L.whist[ww * NB + b] = 0;
             L.woff[ww * NB + b] = (uint16_t)run;
@@ -431,12 +439,12 @@ __device__ inline void bins_scan(const int32_t *src, int32_t *base, int nb, int 
     __syncthreads();
 }
 
-// Regroup: `m` sorted entries (INITIAL: suffixes in vcur, ordered by their first SA_INIT_SYMS symbols;
-// otherwise records sorted by (k1, sequence order)) -> slots, new group starts, bitmaps, next digit counts.
+// Regroup: `m` sorted records (INITIAL: (first SA_INIT_SYMS symbols, suffix) in symbol order, one group;
+// otherwise (k1, k2, suffix) sorted by (k1, sequence order)) -> slots, new group starts, bitmaps, next digit counts.
 // Returns the number of suffixes that still share their group.
 template <bool INITIAL, int DB>
-__device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uint8_t *T, uint32_t n, const int32_t *vcur,
-                                      const uint64_t *rec, uint32_t m, int32_t *sa, int32_t *rk, int tid) {
+__device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uint64_t *rec, uint32_t m, int32_t *sa,
+                                      int32_t *rk, int tid) {
     constexpr int NB = 1 << DB;
     const int lane = tid & 63, w = tid >> 6;
     int tileK = -1, tileS = -1;
@@ -452,23 +460,19 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             key[s] = 0;
             p[s] = 0;
             if (u < m) {
-                if (INITIAL) {
-                    p[s] = vcur[u];
-                    key[s] = init_key(T, n, (uint32_t)p[s]);
-                } else {
-                    const uint64_t r = rec[u];
-                    p[s] = (int)(r & 0xFFFFFu);
-                    key[s] = r >> 20;
-                }
+                const uint64_t r = rec[u];
+                p[s] = (int)(r & 0xFFFFFu);
+                key[s] = r >> 20;
             }
         }
         // neighbours across the wave's span (uniform loads)
         uint64_t pkey = 0, nkey = 0;
         const uint32_t un = wb + SA_WSPAN;
-        if (wb > 0 && wb < m) pkey = INITIAL ? init_key(T, n, (uint32_t)vcur[wb - 1]) : (rec[wb - 1] >> 20);
-        if (un < m) nkey = INITIAL ? init_key(T, n, (uint32_t)vcur[un]) : (rec[un] >> 20);
+        if (wb > 0 && wb < m) pkey = rec[wb - 1] >> 20;
+        if (un < m) nkey = rec[un] >> 20;
 
-        int fK[SA_K], fS[SA_K];
+        // per entry: bit 0 = first of its group, bit 1 = first of its (group, second key) run, bit 2 = alone
+        int fl[SA_K];
 #pragma unroll
         for (int s = 0; s < SA_K; ++s) {
             const uint32_t u = wb + s * 64 + lane;
@@ -477,22 +481,22 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             if (lane == 0) q = (s == 0) ? pkey : q63;
             const bool valid = u < m;
             const bool first = (u == 0);
-            fS[s] = valid && (first || key[s] != q);
-            fK[s] = valid && (first || (!INITIAL && (key[s] >> 20) != (q >> 20)));
+            const bool fS = valid && (first || key[s] != q);
+            const bool fK = valid && (first || (!INITIAL && (key[s] >> 20) != (q >> 20)));
+            fl[s] = (fK ? 1 : 0) | (fS ? 2 : 0);
         }
-        int single[SA_K];
         int gKl[SA_K], gSl[SA_K];
         int runK = -1, runS = -1;
 #pragma unroll
         for (int s = 0; s < SA_K; ++s) {
             const uint32_t u = wb + s * 64 + lane;
-            int nf = __shfl_down(fS[s], 1);
-            const int nf0 = (s + 1 < SA_K) ? __shfl(fS[s + 1 < SA_K ? s + 1 : s], 0) : 0;
+            int nf = __shfl_down(fl[s], 1) & 2;
+            const int nf0 = __shfl(fl[s + 1 < SA_K ? s + 1 : s], 0) & 2;  // executed by all lanes
             if (lane == 63) nf = (s + 1 < SA_K) ? nf0 : ((un < m) ? (int)(nkey != key[s]) : 1);
             if (u + 1 >= m) nf = 1;
-            single[s] = fS[s] && nf;
-            int gK = wave_incl_max(fK[s] ? (int)u : -1, lane);
-            int gS = wave_incl_max(fS[s] ? (int)u : -1, lane);
+            if ((fl[s] & 2) && nf) fl[s] |= 4;
+            int gK = wave_incl_max((fl[s] & 1) ? (int)u : -1, lane);
+            int gS = wave_incl_max((fl[s] & 2) ? (int)u : -1, lane);
             gK = max(gK, runK);
             gS = max(gS, runS);
             runK = __shfl(gK, 63);
@@ -506,7 +510,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
         }
         __syncthreads();
         int cinK = tileK, cinS = tileS;
-        for (int ww = 0; ww < SA_WAVES; ++ww) {
+        for (int ww = 0; ww < SAM_WAVES; ++ww) {
             const int a = cy.a[par][ww], b = cy.b[par][ww];
             if (ww < w) {
                 cinK = max(cinK, a);
@@ -523,7 +527,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             const int k1 = INITIAL ? 0 : (int)(key[s] >> 20);
             const int slot = k1 + ((int)u - gK);
             const int nr = k1 + (gS - gK);
-            const bool sgl = single[s];
+            const bool fK = fl[s] & 1, fS = fl[s] & 2, sgl = fl[s] & 4;
             if (valid) {
                 sa[slot] = p[s];
                 rk[p[s]] = nr;
@@ -532,11 +536,11 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
                 } else if (sgl) {
                     atomicAnd(&L.act[(uint32_t)p[s] >> 5], ~(1u << (p[s] & 31)));
                 }
-                if (fS[s] && (INITIAL || !fK[s])) atomicOr(&L.gb[(uint32_t)slot >> 5], 1u << (slot & 31));
+                if (fS && (INITIAL || !fK)) atomicOr(&L.gb[(uint32_t)slot >> 5], 1u << (slot & 31));
             }
             // digit counts of the keys of the next round, one update per run of equal group starts
             const uint64_t vmask = __ballot(valid);
-            const bool head = valid && (fS[s] || lane == 0);
+            const bool head = valid && (fS || lane == 0);
             const uint64_t heads = __ballot(head);
             if (head && !sgl) {
                 const uint64_t rest = (lane == 63) ? 0ull : (heads >> (lane + 1));
@@ -551,13 +555,13 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
     if (lane == 0) cy.wcount[w] = (int)rem;
     __syncthreads();
     uint32_t total = 0;
-    for (int ww = 0; ww < SA_WAVES; ++ww) total += (uint32_t)cy.wcount[ww];
+    for (int ww = 0; ww < SAM_WAVES; ++ww) total += (uint32_t)cy.wcount[ww];
     __syncthreads();
     return total;
 }
 
 template <int DB>
-__global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
+__global__ __launch_bounds__(SAM_THREADS) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
     constexpr int NB = 1 << DB;
     constexpr int MASK = NB - 1;
     __shared__ SaCarry cy;
@@ -579,15 +583,14 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
     const uint32_t words = ((N + 63) / 64) * 2;  // bitmap words, whole 64-bit groups
     const SaLds<DB> L(dyn_lds, words);
     uint64_t *recA = wk.recA + sg.off, *recB = wk.recB + sg.off;
-    int32_t *vA = (int32_t *)recA, *vB = (int32_t *)recB;
 
-    for (uint32_t x = tid; x < 2 * words; x += SA_THREADS) L.act[x] = 0;  // act and gb
-    for (int x = tid; x < 4 * NB; x += SA_THREADS) L.tstart[x] = 0;       // tstart, base, hl, hh
-    for (int x = tid; x < SA_WAVES * NB; x += SA_THREADS) L.whist[x] = 0;
+    for (uint32_t x = tid; x < 2 * words; x += SAM_THREADS) L.act[x] = 0;  // act and gb
+    for (int x = tid; x < 4 * NB; x += SAM_THREADS) L.tstart[x] = 0;       // tstart, base, hl, hh
+    for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
     __syncthreads();
 
     // ---- byte histogram of the text (hl[c] = occurrences of byte c)
-    for (uint32_t q0 = (uint32_t)w * 64; q0 < n; q0 += SA_THREADS) {
+    for (uint32_t q0 = (uint32_t)w * 64; q0 < n; q0 += SAM_THREADS) {
         const uint32_t q = q0 + lane;
         const bool valid = q < n;
         const int c = valid ? (int)T[q] : 0;
@@ -596,45 +599,43 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
     }
     __syncthreads();
 
-    // ---- initial order by the first SA_INIT_SYMS symbols: LSD passes, digit read from the text
+    // ---- initial order by the first SA_INIT_SYMS symbols: LSD passes over records (symbols << 20 | suffix);
+    //      the first pass builds the records from the text, the others only move them
     {
-        const int32_t *vin = nullptr;  // pass 0 reads the identity
-        int32_t *vout = vA;
+        const uint64_t *rin = nullptr;
+        uint64_t *rout = recA;
         for (int pass = 0; pass < SA_INIT_SYMS; ++pass) {
             const uint32_t d = (uint32_t)(SA_INIT_SYMS - 1 - pass);  // symbol index used by this pass
+            const int shift = 20 + 9 * pass;
             // bin totals: the symbols at p + d for p in [0, N) are the text without its first d bytes, then
             // min(d, n) + 1 sentinels
             const uint32_t dd = min(d, n);
-            if (tid < NB) {
+            for (int b = tid; b < NB; b += SAM_THREADS) {
                 int v = 0;
-                if (tid == 0) {
+                if (b == 0) {
                     v = (int)dd + 1;
-                } else if (tid <= 256) {
-                    v = L.hl[tid - 1];
-                    for (uint32_t q = 0; q < dd; ++q) v -= ((int)T[q] + 1 == tid) ? 1 : 0;
+                } else if (b <= 256) {
+                    v = L.hl[b - 1];
+                    for (uint32_t q = 0; q < dd; ++q) v -= ((int)T[q] + 1 == b) ? 1 : 0;
                 }
-                L.hh[tid] = v;
+                L.hh[b] = v;
             }
             __syncthreads();
             bins_scan(L.hh, L.base, NB, tid);
             for (uint32_t t0 = 0; t0 < N; t0 += SA_TILE) {
                 const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
-                int val[SA_K], sym[SA_K], loc[SA_K];
+                uint64_t r[SA_K];
+                int loc[SA_K];
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     const uint32_t e = wb + s * 64 + lane;
-                    val[s] = (e < N) ? (vin ? vin[e] : (int)e) : 0;
+                    r[s] = 0;
+                    if (e < N) r[s] = rin ? rin[e] : ((init_key(T, n, e) << 20) | (uint64_t)e);
                 }
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     const uint32_t e = wb + s * 64 + lane;
-                    const uint32_t q = (uint32_t)val[s] + d;
-                    sym[s] = (e < N && q < n) ? (int)T[q] + 1 : 0;
-                }
-#pragma unroll
-                for (int s = 0; s < SA_K; ++s) {
-                    const uint32_t e = wb + s * 64 + lane;
-                    loc[s] = tile_rank<9>(L.whist + w * NB, sym[s], e < N, lane);
+                    loc[s] = tile_rank<9>(L.whist + w * NB, (int)(r[s] >> shift) & 511, e < N, lane);
                 }
                 __syncthreads();
                 tile_offsets<DB>(L, tid);
@@ -642,19 +643,20 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     const uint32_t e = wb + s * 64 + lane;
-                    if (e < N) vout[L.tstart[sym[s]] + (int)L.woff[w * NB + sym[s]] + loc[s]] = val[s];
+                    const int sym = (int)(r[s] >> shift) & 511;
+                    if (e < N) rout[L.tstart[sym] + (int)L.woff[w * NB + sym] + loc[s]] = r[s];
                 }
             }
             __syncthreads();
-            vin = vout;
-            vout = (vout == vA) ? vB : vA;
+            rin = rout;
+            rout = (rout == recA) ? recB : recA;
         }
     }
-    const int32_t *vcur = (SA_INIT_SYMS & 1) ? vA : vB;
-    for (int x = tid; x < 2 * NB; x += SA_THREADS) L.hl[x] = 0;  // hl, hh
+    const uint64_t *rcur = (SA_INIT_SYMS & 1) ? recA : recB;
+    for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh
     __syncthreads();
 
-    uint32_t m = sa_regroup<true, DB>(L, cy, T, n, vcur, nullptr, N, sa, rk, tid);
+    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid);
     uint32_t h = (uint32_t)SA_INIT_SYMS;
     while (m != 0 && h < N && --max_rounds >= 0) {
         // ---- S1: active members of the sequence p = SA[j] - h -> records, scattered by the low digit of k1
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
                 __syncthreads();
                 tile_offsets<DB>(L, tid);
                 int cin = tileG;
-                for (int ww = 0; ww < SA_WAVES; ++ww) {
+                for (int ww = 0; ww < SAM_WAVES; ++ww) {
                     const int g = cy.a[par][ww];
                     if (ww < w) cin = max(cin, g);
                     tileG = max(tileG, g);
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
         __syncthreads();
         // ---- S2: records by the high digit of k1
         bins_scan(L.hh, L.base, NB, tid);
-        for (int x = tid; x < 2 * NB; x += SA_THREADS) L.hl[x] = 0;  // hl, hh: refilled by the regroup below
+        for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh: refilled by the regroup below
         for (uint32_t t0 = 0; t0 < m; t0 += SA_TILE) {
             const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
             uint64_t r[SA_K];
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_kernel(const Seg *segs, c
         }
         __syncthreads();
         // ---- D: new groups
-        m = sa_regroup<false, DB>(L, cy, T, n, nullptr, recB, m, sa, rk, tid);
+        m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid);
         h *= 2;
     }
 }
@@ -859,10 +861,10 @@ void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const u
         attr_set = true;
     }
     if (N <= (1u << 18)) {
-        hipLaunchKernelGGL(sa_build_kernel<9>, dim3(n_segs), dim3(SA_THREADS), SaLds<9>::bytes(words), stream, d_segs,
+        hipLaunchKernelGGL(sa_build_kernel<9>, dim3(n_segs), dim3(SAM_THREADS), SaLds<9>::bytes(words), stream, d_segs,
                            d_text, wk, max_rounds);
     } else if (N <= SA_BITMAP_MAX_N) {
-        hipLaunchKernelGGL(sa_build_kernel<10>, dim3(n_segs), dim3(SA_THREADS), SaLds<10>::bytes(words), stream, d_segs,
+        hipLaunchKernelGGL(sa_build_kernel<10>, dim3(n_segs), dim3(SAM_THREADS), SaLds<10>::bytes(words), stream, d_segs,
                            d_text, wk, max_rounds);
     } else {
         hipLaunchKernelGGL(sa_build_full_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, d_text, wk);
