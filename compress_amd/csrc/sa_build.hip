@@ -337,6 +337,14 @@ constexpr int SA_INIT_SYMS = 4;  // depth of the initial sort (symbols compared 
 #ifndef SA_MAIN_K
 #define SA_MAIN_K 8
 #endif
+#ifndef SA_USE_STAGE
+#define SA_USE_STAGE 0
+#endif
+#ifndef SA_USE_MTAB
+#define SA_USE_MTAB 1
+#endif
+constexpr bool SA_MTAB = SA_USE_MTAB;    // lanes with equal digits find each other through a bit table in LDS
+constexpr bool SA_STAGE = SA_USE_STAGE;  // reorder every tile in LDS so that the scatter writes runs of records
 constexpr int SAM_THREADS = SA_MAIN_THREADS;
 constexpr int SAM_WAVES = SAM_THREADS / 64;
 constexpr int SA_K = SA_MAIN_K;  // sequence entries per thread and tile
@@ -366,24 +374,34 @@ __device__ inline uint64_t match_bits(int d, uint64_t amask) {
 template <int DB>
 struct SaLds {
     static constexpr int NB = 1 << DB;
-    uint16_t *whist;   // [SAM_WAVES][NB] entries of the current tile per wave and bin (zero between tiles)
-    uint16_t *woff;    // [SAM_WAVES][NB] tile-local offset of wave w's entries inside bin b
-    int32_t *tstart;   // [NB] output index of the tile's first entry of bin b
-    int32_t *base;     // [NB] running output index of bin b
-    int32_t *hl, *hh;  // [NB] digit counts of the next round's keys (low / high digit)
     uint32_t *act;     // bit p: suffix p still shares its group
-    uint32_t *gb;      // bit j: slot j of the suffix array starts a group
+    int32_t *base;     // [NB] running output index of bin b
+    int32_t *delta;    // [NB] output index minus staging index for the tile's entries of bin b
+    int32_t *tpos;     // [NB] staging index of the tile's first entry of bin b
+    int32_t *hl, *hh;  // [NB] digit counts of the next round's keys (low / high digit)
+    int32_t *wtot;     // [16] tile entries per wave of bin threads
+    uint16_t *whist;   // [SAM_WAVES][NB] entries of the current tile per wave and bin (zero between tiles)
+    uint16_t *woff;    // [SAM_WAVES][NB] offset of wave w's entries inside the tile's bin b
+    uint64_t *stage;   // [SA_TILE] the tile's records in bin order
+    uint64_t *mtab;    // [SAM_WAVES][NB] per wave: lanes holding digit d (zero between steps)
     __device__ SaLds(uint32_t *mem, uint32_t words) {
         act = mem;
-        gb = act + words;
-        tstart = (int32_t *)(gb + words);
-        base = tstart + NB;
-        hl = base + NB;
+        base = (int32_t *)(act + words);
+        delta = base + NB;
+        tpos = delta + NB;
+        hl = tpos + NB;
         hh = hl + NB;
-        whist = (uint16_t *)(hh + NB);
+        wtot = hh + NB;
+        whist = (uint16_t *)(wtot + 16);
         woff = whist + SAM_WAVES * NB;
+        stage = (uint64_t *)(woff + SAM_WAVES * NB);
+        mtab = stage + (SA_STAGE ? SA_TILE : 0);
     }
-    static size_t bytes(uint32_t words) { return (size_t)words * 8 + (size_t)NB * 16 + (size_t)SAM_WAVES * NB * 4; }
+    // words: bitmap words (even)
+    static size_t bytes(uint32_t words) {
+        return (size_t)words * 4 + ((size_t)NB * 5 + 16) * 4 + (size_t)SAM_WAVES * NB * 4 + (SA_STAGE ? (size_t)SA_TILE * 8 : 0) +
+               (SA_MTAB ? (size_t)SAM_WAVES * NB * 8 : 0);
+    }
 };
 
 struct SaCarry {
@@ -392,11 +410,45 @@ struct SaCarry {
     int32_t wcount[SAM_WAVES];
 };
 
+// lanes of the wave (among `valid`) holding the same digit as this lane.  The most frequent digits are found
+// by two leader votes; the rest meet in the wave's bit table (one 64-bit word per digit).
+template <int RB>
+__device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lane) {
+    if (!SA_MTAB) return match_bits<RB>(d, __ballot(valid));
+    uint64_t peers = 0;
+    bool todo = valid;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint64_t rem = __ballot(todo);
+        if (rem) {
+            const int dl = __shfl(d, (int)__builtin_ctzll(rem));
+            const bool eq = todo && d == dl;
+            const uint64_t e = __ballot(eq);
+            if (eq) {
+                peers = e;
+                todo = false;
+            }
+        }
+    }
+    if (__ballot(todo)) {
+        if (todo) atomicOr((unsigned long long *)&mrow[d], 1ull << lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (todo) peers = mrow[d];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (todo) mrow[d] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return peers;
+}
+
 // rank of this lane's entry among the entries of its wave's tile part with the same digit (stable)
-template <int DB>
-__device__ inline int tile_rank(uint16_t *wrow, int d, bool valid, int lane) {
-    const uint64_t amask = __ballot(valid);
-    const uint64_t peers = match_bits<DB>(d, amask);
+template <int RB, int DB>
+__device__ inline int tile_rank(const SaLds<DB> &L, int w, int d, bool valid, int lane) {
+    uint16_t *wrow = L.whist + w * (1 << DB);
+    const uint64_t peers = wave_peers<RB>(L.mtab + w * (1 << DB), d, valid, lane);
     const int cnt = __popcll(peers);
     const int rank = __popcll(peers & lanemask_lt(lane));
     const int lh = valid ? (int)wrow[d] : 0;
@@ -406,22 +458,82 @@ __device__ inline int tile_rank(uint16_t *wrow, int d, bool valid, int lane) {
     return lh + rank;
 }
 
-// per-wave tile counts -> offsets; advances the running bases (call between two barriers)
+// After every wave has ranked its part of the tile: per-wave counts -> offsets inside the tile's bins, bins ->
+// staging positions (a scan over the bins) and output positions (the running bases advance).  Three barriers.
+// Returns the number of entries of the tile.
 template <int DB>
-__device__ inline void tile_offsets(const SaLds<DB> &L, int tid) {
+__device__ inline int tile_prepare(const SaLds<DB> &L, int tid) {
     constexpr int NB = 1 << DB;
-    for (int b = tid; b < NB; b += SAM_THREADS) {
-        int run = 0;
+    constexpr int BPT = NB > SAM_THREADS ? NB / SAM_THREADS : 1;  // consecutive bins per bin thread
+    constexpr int NBT = NB / BPT;
+    const int lane = tid & 63, w = tid >> 6;
+    __syncthreads();
+    int run[BPT], gs[BPT];
+    int tot = 0;
 #pragma unroll
-        for (int ww = 0; ww < SAM_WAVES; ++ww) {
-            const int t = L.whist[ww * NB + b];
-            L.whist[ww * NB + b] = 0;
-            L.woff[ww * NB + b] = (uint16_t)run;
-            run += t;
+    for (int i = 0; i < BPT; ++i) {
+        run[i] = 0;
+        gs[i] = 0;
+        if (tid < NBT) {
+            const int b = tid * BPT + i;
+            int r = 0;
+#pragma unroll
+            for (int ww = 0; ww < SAM_WAVES; ++ww) {
+                const int t = L.whist[ww * NB + b];
+                L.whist[ww * NB + b] = 0;
+                L.woff[ww * NB + b] = (uint16_t)r;
+                r += t;
+            }
+            run[i] = r;
+            gs[i] = L.base[b];
+            L.base[b] = gs[i] + r;
+            tot += r;
         }
-        const int s = L.base[b];
-        L.tstart[b] = s;
-        L.base[b] = s + run;
+    }
+    const int inc = wave_incl_add(tot, lane);
+    if (lane == 63) L.wtot[w] = inc;
+    __syncthreads();
+    int carry = 0, total = 0;
+#pragma unroll
+    for (int ww = 0; ww < SAM_WAVES; ++ww) {
+        const int t = L.wtot[ww];
+        if (ww < w) carry += t;
+        total += t;
+    }
+    if (tid < NBT) {
+        int pre = carry + inc - tot;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int b = tid * BPT + i;
+            L.tpos[b] = pre;
+            L.delta[b] = gs[i] - pre;
+            pre += run[i];
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
+// one record of the tile: to its staging position, or straight to the output
+template <int DB>
+__device__ inline void tile_put(const SaLds<DB> &L, uint64_t *out, int d, int wrow_off, int loc, uint64_t r) {
+    const int pos = L.tpos[d] + (int)L.woff[wrow_off + d] + loc;
+    if (SA_STAGE) L.stage[pos] = r;
+    else out[L.delta[d] + pos] = r;
+}
+
+// the staged tile (bin order) -> out, consecutive lanes write consecutive records of a bin
+template <int DB>
+__device__ inline void tile_flush(const SaLds<DB> &L, uint64_t *out, int sh, int msk, int tile_n, int tid) {
+    if (!SA_STAGE) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SA_K; ++i) {
+        const int pos = i * SAM_THREADS + tid;
+        if (pos < tile_n) {
+            const uint64_t r = L.stage[pos];
+            out[L.delta[(int)(r >> sh) & msk] + pos] = r;
+        }
     }
 }
 
@@ -527,16 +639,15 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             const int k1 = INITIAL ? 0 : (int)(key[s] >> 20);
             const int slot = k1 + ((int)u - gK);
             const int nr = k1 + (gS - gK);
-            const bool fK = fl[s] & 1, fS = fl[s] & 2, sgl = fl[s] & 4;
+            const bool fS = fl[s] & 2, sgl = fl[s] & 4;
             if (valid) {
-                sa[slot] = p[s];
+                sa[slot] = p[s] | ((fS && !sgl) ? (int)0x80000000 : 0);  // top bit: first slot of a shared group
                 rk[p[s]] = nr;
                 if (INITIAL) {
                     if (!sgl) atomicOr(&L.act[(uint32_t)p[s] >> 5], 1u << (p[s] & 31));
                 } else if (sgl) {
                     atomicAnd(&L.act[(uint32_t)p[s] >> 5], ~(1u << (p[s] & 31)));
                 }
-                if (fS && (INITIAL || !fK)) atomicOr(&L.gb[(uint32_t)slot >> 5], 1u << (slot & 31));
             }
             // digit counts of the keys of the next round, one update per run of equal group starts
             const uint64_t vmask = __ballot(valid);
@@ -561,7 +672,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
 }
 
 template <int DB>
-__global__ __launch_bounds__(SAM_THREADS) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
+__global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM_WAVES / 2, SAM_WAVES / 2))) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
     constexpr int NB = 1 << DB;
     constexpr int MASK = NB - 1;
     __shared__ SaCarry cy;
@@ -580,13 +691,15 @@ __global__ __launch_bounds__(SAM_THREADS) void sa_build_kernel(const Seg *segs, 
         }
         return;
     }
-    const uint32_t words = ((N + 63) / 64) * 2;  // bitmap words, whole 64-bit groups
+    const uint32_t words = ((N + 63) / 64) * 2;  // bitmap words (even)
     const SaLds<DB> L(dyn_lds, words);
     uint64_t *recA = wk.recA + sg.off, *recB = wk.recB + sg.off;
 
-    for (uint32_t x = tid; x < 2 * words; x += SAM_THREADS) L.act[x] = 0;  // act and gb
-    for (int x = tid; x < 4 * NB; x += SAM_THREADS) L.tstart[x] = 0;       // tstart, base, hl, hh
+    for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;
+    for (int x = tid; x < 5 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh
     for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
+    if (SA_MTAB)
+        for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.mtab[x] = 0;
     __syncthreads();
 
     // ---- byte histogram of the text (hl[c] = occurrences of byte c)
@@ -635,17 +748,16 @@ __global__ __launch_bounds__(SAM_THREADS) void sa_build_kernel(const Seg *segs, 
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     const uint32_t e = wb + s * 64 + lane;
-                    loc[s] = tile_rank<9>(L.whist + w * NB, (int)(r[s] >> shift) & 511, e < N, lane);
+                    loc[s] = tile_rank<9, DB>(L, w, (int)(r[s] >> shift) & 511, e < N, lane);
                 }
-                __syncthreads();
-                tile_offsets<DB>(L, tid);
-                __syncthreads();
+                const int tile_n = tile_prepare<DB>(L, tid);
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     const uint32_t e = wb + s * 64 + lane;
                     const int sym = (int)(r[s] >> shift) & 511;
-                    if (e < N) rout[L.tstart[sym] + (int)L.woff[w * NB + sym] + loc[s]] = r[s];
+                    if (e < N) tile_put<DB>(L, rout, sym, w * NB, loc[s], r[s]);
                 }
+                tile_flush<DB>(L, rout, shift, 511, tile_n, tid);
             }
             __syncthreads();
             rin = rout;
@@ -677,7 +789,7 @@ __global__ __launch_bounds__(SAM_THREADS) void sa_build_kernel(const Seg *segs, 
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     const uint32_t j = wb + s * 64 + lane;
-                    const uint32_t sx = (uint32_t)sv[s];
+                    const uint32_t sx = (uint32_t)sv[s] & 0x7FFFFFFFu;
                     const uint32_t pp = sx >= h ? sx - h : N - h + sx;
                     p[s] = (int)pp;
                     a[s] = (j < N) && ((L.act[pp >> 5] >> (pp & 31)) & 1u);
@@ -686,33 +798,36 @@ __global__ __launch_bounds__(SAM_THREADS) void sa_build_kernel(const Seg *segs, 
                 int runG = -1;
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
-                    const uint32_t j0 = wb + s * 64;
-                    uint64_t gw = 0;
-                    if (j0 < N) gw = (uint64_t)L.gb[j0 >> 5] | ((uint64_t)L.gb[(j0 >> 5) + 1] << 32);
+                    const uint32_t j = wb + s * 64 + lane;
+                    const uint32_t sx = (uint32_t)sv[s] & 0x7FFFFFFFu;
+                    // slot j starts a group: marked, or its suffix is alone in its group
+                    const bool gstart = (j < N) && ((sv[s] < 0) || !((L.act[sx >> 5] >> (sx & 31)) & 1u));
+                    const uint64_t gw = __ballot(gstart);
                     const uint64_t le = gw & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-                    k2[s] = le ? (int)j0 + 63 - (int)__builtin_clzll(le) : runG;
-                    if (gw) runG = (int)j0 + 63 - (int)__builtin_clzll(gw);
-                    loc[s] = tile_rank<DB>(L.whist + w * NB, k1[s] & MASK, a[s], lane);
+                    const int j0 = (int)(wb + s * 64);
+                    k2[s] = le ? j0 + 63 - (int)__builtin_clzll(le) : runG;
+                    if (gw) runG = j0 + 63 - (int)__builtin_clzll(gw);
+                    loc[s] = 0;
+                    if (__ballot(a[s])) loc[s] = tile_rank<DB, DB>(L, w, k1[s] & MASK, a[s], lane);
                 }
                 if (lane == 0) cy.a[par][w] = runG;
-                __syncthreads();
-                tile_offsets<DB>(L, tid);
+                const int tile_n = tile_prepare<DB>(L, tid);
                 int cin = tileG;
                 for (int ww = 0; ww < SAM_WAVES; ++ww) {
                     const int g = cy.a[par][ww];
                     if (ww < w) cin = max(cin, g);
                     tileG = max(tileG, g);
                 }
-                __syncthreads();
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     if (a[s]) {
                         const int d = k1[s] & MASK;
                         const int g = k2[s] < 0 ? cin : k2[s];
-                        recA[L.tstart[d] + (int)L.woff[w * NB + d] + loc[s]] =
-                            ((uint64_t)(uint32_t)k1[s] << 40) | ((uint64_t)(uint32_t)g << 20) | (uint64_t)(uint32_t)p[s];
+                        tile_put<DB>(L, recA, d, w * NB, loc[s],
+                                     ((uint64_t)(uint32_t)k1[s] << 40) | ((uint64_t)(uint32_t)g << 20) | (uint64_t)(uint32_t)p[s]);
                     }
                 }
+                tile_flush<DB>(L, recA, 40, MASK, tile_n, tid);
             }
         }
         __syncthreads();
@@ -731,17 +846,16 @@ __global__ __launch_bounds__(SAM_THREADS) void sa_build_kernel(const Seg *segs, 
 #pragma unroll
             for (int s = 0; s < SA_K; ++s) {
                 const uint32_t u = wb + s * 64 + lane;
-                loc[s] = tile_rank<DB>(L.whist + w * NB, (int)(r[s] >> (40 + DB)), u < m, lane);
+                loc[s] = tile_rank<DB, DB>(L, w, (int)(r[s] >> (40 + DB)) & MASK, u < m, lane);
             }
-            __syncthreads();
-            tile_offsets<DB>(L, tid);
-            __syncthreads();
+            const int tile_n = tile_prepare<DB>(L, tid);
 #pragma unroll
             for (int s = 0; s < SA_K; ++s) {
                 const uint32_t u = wb + s * 64 + lane;
-                const int d = (int)(r[s] >> (40 + DB));
-                if (u < m) recB[L.tstart[d] + (int)L.woff[w * NB + d] + loc[s]] = r[s];
+                const int d = (int)(r[s] >> (40 + DB)) & MASK;
+                if (u < m) tile_put<DB>(L, recB, d, w * NB, loc[s], r[s]);
             }
+            tile_flush<DB>(L, recB, 40 + DB, MASK, tile_n, tid);
         }
         __syncthreads();
         // ---- D: new groups
