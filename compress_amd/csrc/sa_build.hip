@@ -862,6 +862,10 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid);
         h *= 2;
     }
+    if (m != 0) {  // rounds cut short (timing experiments): drop the group marks so that SA stays a permutation
+        __syncthreads();
+        for (uint32_t j = tid; j < N; j += SAM_THREADS) sa[j] &= 0x7FFFFFFF;
+    }
 }
 
 // ---- window index: ranks regrouped by the 16 KiB chunk of their position (stable in rank order) ------
