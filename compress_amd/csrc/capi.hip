@@ -101,6 +101,7 @@ struct mi355_lzss_batch {
     // per-position arrays
     DevBuf text, sortA, sortB, rkA, rkB, flags, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
     DevBuf pmin1, pmax1, pmin2, pmax2, samin1, samin2;  // per 64 entries
+    DevBuf cdir;                                        // per 64 ranks and chunk
     DevBuf entry, tilebit, headb, tailb;  // per 256-tile
     DevBuf segs, nbits, out_off, out_len, status;  // per blob
     DevBuf out;                                    // compressed bytes, blob b at out_off[b]
@@ -179,6 +180,8 @@ static BatchIndex batch_index(mi355_lzss_batch *b) {
     ix.pmin1 = b->pmin1.as<int32_t>(); ix.pmax1 = b->pmax1.as<int32_t>();
     ix.pmin2 = b->pmin2.as<int32_t>(); ix.pmax2 = b->pmax2.as<int32_t>();
     ix.samin1 = b->samin1.as<int32_t>(); ix.samin2 = b->samin2.as<int32_t>();
+    ix.cdir = b->cdir.as<uint16_t>();
+    ix.nch = std::max<uint32_t>(1, (b->max_n + LZSS_SHORT_WINDOW - 1) / LZSS_SHORT_WINDOW);
     return ix;
 }
 static WalkWork walk_work(mi355_lzss_batch *b) {
@@ -220,7 +223,7 @@ extern "C" void mi355_lzss_batch_destroy(mi355_lzss_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     DevBuf *bufs[] = {&b->text, &b->sortA, &b->sortB, &b->rkA, &b->rkB, &b->flags, &b->sa, &b->isa,
-                      &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
+                      &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->cdir, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
                       &b->headb, &b->tailb, &b->segs, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->out,
                       &b->d_cin, &b->d_cin_off, &b->d_dout, &b->d_dout_off, &b->d_dlen, &b->d_dstatus};
     for (DevBuf *d : bufs) d->release();
@@ -254,6 +257,10 @@ extern "C" int mi355_lzss_batch_upload(mi355_lzss_batch *b, const uint8_t *in, c
     }
     if ((rc = batch_reserve(b, std::max<uint32_t>(n_blobs, 1), std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
     if ((rc = b->h_stage.ensure((size_t)std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
+    {
+        const uint64_t nch = std::max<uint32_t>(1, (max_n + LZSS_SHORT_WINDOW - 1) / LZSS_SHORT_WINDOW);
+        if ((rc = b->cdir.ensure((size_t)((std::max<uint64_t>(elems, SEG_ALIGN) / 64 + 1) * nch * 2))) != 0) return rc;
+    }
     uint8_t *st = b->h_stage.as<uint8_t>();
     for (uint32_t k = 0; k < n_blobs; ++k) {
         const Seg &s = b->h_segs[k];

@@ -23,7 +23,10 @@ struct Seg {
 
 constexpr uint32_t SEG_ALIGN = 256;   // segment stride granularity; >= 16 bytes of zero padding follow each text
 constexpr uint32_t SEG_PAD = 64;      // stride = align(n + SEG_PAD)
-constexpr int HEAD = 512;             // positions below HEAD are matched by brute force (match_head_kernel)
+#ifndef LZSS_HEAD
+#define LZSS_HEAD 256
+#endif
+constexpr int HEAD = LZSS_HEAD;         // positions below HEAD are matched by brute force (match_head_kernel)
 
 // packed per-position result of bestBackref (compress.go:146-173)
 constexpr uint32_t RES_NONE = 0u;

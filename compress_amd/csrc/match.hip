@@ -123,26 +123,13 @@ __device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen
     return lcp_bytes(pat, D.T + q, from, maxLen < avail ? maxLen : avail);
 }
 
-// Longest prefix of pat[0:maxLen) occurring in the dictionary, and its smallest-rank occurrence.
-// minLen: shorter results are of no use to the caller (lets an empty two-byte bucket end the search).
-__device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int maxLen, int minLen, int &Ld, int &pd, int g_ablate) {
-    Ld = 0;
-    pd = -1;
-    // invariant: suffix(lo) < pat <= suffix(hi); rank 0 is the sentinel, rank n+1 is virtual
-    int lo = 0, hi = (int)D.n + 1;
-    if (maxLen >= 2) {
-        const uint32_t b = ((uint32_t)pat[0] << 8) | pat[1];
-        const int s = D.bstart[b], e = D.bend[b];
-        if (s < e) {  // every suffix sharing two bytes with pat is in [s, e)
-            lo = s - 1;
-            hi = e;
-        } else if (minLen >= 2) {
-            return;  // nothing in the dictionary shares two bytes with pat
-        }
-    }
+// Binary search of pat[0:maxLen) among the dictionary suffixes.  Invariant: suffix(lo) < pat <= suffix(hi); rank 0 is
+// the sentinel, rank n+1 is virtual.  Narrows [lo, hi] until hi == lo + 1; hi is then the lower bound of pat.
+// llo / lhi: lower bounds of lcp(pat, suffix(lo)) / lcp(pat, suffix(hi)), exact when set by a text compare.
+__device__ inline void dict_search(const DictView &D, const uint8_t *pat, int maxLen, int &lo, int &hi, int &llo, int &lhi,
+                                   int g_ablate) {
     uint64_t pk = __builtin_bswap64(ld8(pat));
     if (maxLen < 8) pk &= ~0ull << (8 * (8 - maxLen));
-    int llo = 0, lhi = 0;  // lower bounds of lcp(pat, suffix(lo)) / lcp(pat, suffix(hi)), exact when set by a text compare
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         const uint64_t kq = D.key[mid];
@@ -165,6 +152,28 @@ __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int ma
         }
         if (suffix_less) { lo = mid; llo = o; } else { hi = mid; lhi = o; }
     }
+}
+
+// the bracket of every suffix sharing two bytes with pat; false if there is none
+__device__ inline bool dict_bucket(const DictView &D, const uint8_t *pat, int &lo, int &hi) {
+    const uint32_t b = ((uint32_t)pat[0] << 8) | pat[1];
+    const int s = D.bstart[b], e = D.bend[b];
+    if (s >= e) return false;
+    lo = lo > s - 1 ? lo : s - 1;
+    hi = hi < e ? hi : e;
+    return true;
+}
+
+// Longest prefix of pat[0:maxLen) occurring in the dictionary, and its smallest-rank occurrence, searched inside the
+// bracket [lo, hi] (0, n + 1 for the whole dictionary).  minLen: shorter results are of no use to the caller (lets an
+// empty two-byte bucket end the search).
+__device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int maxLen, int minLen, int lo, int hi, int &Ld,
+                                   int &pd, int g_ablate) {
+    Ld = 0;
+    pd = -1;
+    if (maxLen >= 2 && !dict_bucket(D, pat, lo, hi) && minLen >= 2) return;  // nothing shares two bytes with pat
+    int llo = 0, lhi = 0;
+    dict_search(D, pat, maxLen, lo, hi, llo, lhi, g_ablate);
     llo = dict_lcp(D, pat, maxLen, lo, llo);
     lhi = dict_lcp(D, pat, maxLen, hi, lhi);
     Ld = llo > lhi ? llo : lhi;
@@ -177,10 +186,11 @@ __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int ma
     }
 }
 
-// Combine the data-window results with the dictionary and apply the selection rule of
-// compress.go:160-169.  Ls/ps: short window, LL/pL: long window (0 / -1 = none).
-__device__ inline uint32_t select_backref(const DictView &D, const uint8_t *T, int i, int maxLen, int minD, bool dynOK,
-                                          int Ls, int ps, int LL, int pL, int ablate = 0) {
+// Apply the selection rule of compress.go:160-169 to the data-window results (Ls/ps: short window, LL/pL: long
+// window, 0 / -1 = none) and the dictionary result (Ld/pd; the caller consults the dictionary only when
+// dynOK && LL < maxLen, compress.go:460).
+__device__ inline uint32_t select_backref(const DictView &D, int i, int minD, bool dynOK, int Ls, int ps, int LL, int pL,
+                                          int Ld, int pd) {
     int Ldyn = 0;
     uint32_t fdyn = 0;
     if (dynOK) {
@@ -188,13 +198,9 @@ __device__ inline uint32_t select_backref(const DictView &D, const uint8_t *T, i
             Ldyn = LL;
             fdyn = (uint32_t)(i - pL - 1);
         }
-        if (LL < maxLen) {  // compress.go:460: the dictionary is consulted only then
-            int Ld, pd;
-            dict_lookup(D, T + i, maxLen, minD, Ld, pd, ablate);
-            if (Ld >= minD && Ld > LL) {  // compress.go:464: strictly longer
-                Ldyn = Ld;
-                fdyn = (uint32_t)(i + (int)D.n - pd - 1);  // backref.go:66, masked to 21 bits by res_pack
-            }
+        if (Ld >= minD && Ld > LL) {  // compress.go:464: strictly longer
+            Ldyn = Ld;
+            fdyn = (uint32_t)(i + (int)D.n - pd - 1);  // backref.go:66, masked to 21 bits by res_pack
         }
     }
     // short wins iff found and 8*Ls-30 > 8*Ldyn-37, i.e. Ls >= Ldyn (compress.go:165)
@@ -257,10 +263,29 @@ struct SegIndex {  // one segment's view of BatchIndex
     const int32_t *SA;
     const uint16_t *LCP, *b1, *b2;
     const int32_t *KS, *PS, *pmin1, *pmax1, *pmin2, *pmax2, *samin1, *samin2;
+    const uint16_t *cdir;
+    int nch;
     int n;
 };
 
 constexpr int LINEAR_SPAN = 24;  // intervals up to this many ranks are scanned directly
+
+// first entry j in [a, end) of a chunk's rank-ordered list with KS[j] >= lo, a coming from the chunk directory
+// (so at most 64 entries away, a chunk's share of 64 ranks)
+__device__ inline int chunk_lower_bound(const int32_t *KS, int a, int end, int lo) {
+    while (a < end && (a & 3)) {
+        if (KS[a] >= lo) return a;
+        ++a;
+    }
+    while (a < end) {
+        const I4 q = ld_i4(KS + a);  // entries past `end` belong to the padded allocation and are ignored
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (a + t >= end || q.v[t] >= lo) return (a + t < end) ? a + t : end;
+        a += 4;
+    }
+    return end;
+}
 
 // Smallest-rank occurrence inside the SHORT window [ws, i) among the suffixes sharing >= L bytes with
 // rank kdn (which is itself in the window, so the answer is <= kdn).
@@ -275,25 +300,19 @@ __device__ inline int leftmost_short(const SegIndex &S, int kdn, int L, int ws, 
     }
     int best = kdn;
     const int c2 = (i - 1) >> LZSS_SHORT_ADDR_BITS;  // chunk of the window's last position: entries with pos < i
+    const int lo1 = lo < 1 ? 1 : lo;                 // rank 0 is the sentinel, in no chunk
+    const uint16_t *dir = S.cdir + (size_t)((lo1 - 1) >> 6) * S.nch;
     {
         const int beg = c2 << LZSS_SHORT_ADDR_BITS;
         const int end = (beg + LZSS_SHORT_WINDOW) < S.n ? (beg + LZSS_SHORT_WINDOW) : S.n;
-        int a = beg, b = end;
-        while (a < b) {  // first entry of the chunk with rank >= lo
-            const int h = (a + b) >> 1;
-            if (S.KS[h] < lo) a = h + 1; else b = h;
-        }
+        const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2], end, lo1);
         const int j = next_thr<true>(S.PS, S.pmin1, S.pmin2, a, end, i);
         if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
     }
     if (c2 >= 1 && ws < (c2 << LZSS_SHORT_ADDR_BITS)) {  // previous chunk: entries with pos >= ws
         const int beg = (c2 - 1) << LZSS_SHORT_ADDR_BITS;
         const int end = beg + LZSS_SHORT_WINDOW;
-        int a = beg, b = end;
-        while (a < b) {
-            const int h = (a + b) >> 1;
-            if (S.KS[h] < lo) a = h + 1; else b = h;
-        }
+        const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2 - 1], end, lo1);
         const int j = next_thr<false>(S.PS, S.pmax1, S.pmax2, a, end, ws);
         if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
     }
@@ -327,6 +346,16 @@ __device__ inline bool never_queried(const uint8_t *T, int n, int i) {
     return true;
 }
 
+#ifdef MATCH_PROFILE  // per-section clocks summed over all waves (debug builds only)
+__device__ unsigned long long g_mp[16];
+#define MP_DECL long long mp_acc[10] = {}; long long mp_last = clock64();
+#define MP(i) { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); mp_acc[i] += t_ - mp_last; mp_last = t_; }
+#define MP_PRINT if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_mp[q_], (unsigned long long)mp_acc[q_]); atomicAdd(&g_mp[8], 1ull); }
+#else
+#define MP_DECL
+#define MP(i)
+#define MP_PRINT
+#endif
 constexpr int SCAN_CAP = 8;  // x4 ranks a lane walks alone before its wave takes the walk over
 
 __device__ inline int wave_incl_min(int v, int lane) {
@@ -349,6 +378,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
     if ((int)(blockIdx.x * MATCH_THREADS) >= N) return;
     const int lane = threadIdx.x & 63;
     const int r = (int)(blockIdx.x * MATCH_THREADS + threadIdx.x);
+    MP_DECL
     const uint8_t *T = ix.text + sg.off;
     const int32_t *SA = ix.sa + sg.off;
     const uint16_t *LCP = ix.lcp + sg.off;
@@ -377,6 +407,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
     int LupS = 0, pupS = -1, LupL = 0, pupL = -1;
     int LdnS = 0, kdnS = -1, LdnL = 0, kdnL = -1;
 
+    MP(0)
     // ---- nearest in-window neighbours above r (the arrays are padded past N)
     {
         int m = 1 << 20, k = r + 1;
@@ -398,6 +429,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
             }
         }
         if (k >= N) done = true;
+        MP(1)
         for (uint64_t hm = __ballot(!done); hm; hm &= hm - 1) {  // the wave finishes lane t's walk
             const int t = (int)__builtin_ctzll(hm);
             const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
@@ -435,6 +467,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
             }
         }
     }
+    MP(2)
     // ---- nearest in-window neighbours below r: lcp(i, SA[k]) = min LCP[k+1 .. r]; rank 0 is the sentinel
     {
         int m = 1 << 20, k = r - 1, it = 0;
@@ -469,6 +502,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
             }
             done = true;
         }
+        MP(3)
         for (uint64_t hm = __ballot(!done); hm; hm &= hm - 1) {
             const int t = (int)__builtin_ctzll(hm);
             const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
@@ -506,30 +540,40 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
             }
         }
     }
-    if (!work) return;
-
+    MP(4)
     SegIndex S;
     S.SA = SA; S.LCP = LCP; S.b1 = b1; S.b2 = b2;
     S.KS = ix.ks + sg.off; S.PS = ix.ps + sg.off;
     S.pmin1 = ix.pmin1 + sg.off / 64; S.pmax1 = ix.pmax1 + sg.off / 64;
     S.pmin2 = ix.pmin2 + sg.off / 64; S.pmax2 = ix.pmax2 + sg.off / 64;
     S.samin1 = ix.samin1 + sg.off / 64; S.samin2 = ix.samin2 + sg.off / 64;
+    S.cdir = ix.cdir + (sg.off / 64) * ix.nch; S.nch = (int)ix.nch;
     S.n = n;
     // short window
     int Ls = 0, ps = -1;
-    {
+    if (work) {
         const int ld = LdnS >= minS ? LdnS : 0, lu = LupS >= minS ? LupS : 0;
         Ls = ld > lu ? ld : lu;
         if (Ls > 0) ps = (lu > ld) ? pupS : ((ablate & 2) ? SA[kdnS] : leftmost_short(S, kdnS, Ls, wsS, i));
     }
+    MP(5)
     // long window
     int LL = 0, pL = -1;
-    if (dynOK) {
+    if (work && dynOK) {
         const int ld = LdnL >= minD ? LdnL : 0, lu = LupL >= minD ? LupL : 0;
         LL = ld > lu ? ld : lu;
         if (LL > 0) pL = (lu > ld) ? pupL : ((ablate & 2) ? SA[kdnL] : leftmost_long(S, kdnL, LL, wsL, i));
     }
-    res[sg.off + i] = select_backref(D, T, i, maxLen, minD, dynOK && !(ablate & 1), Ls, ps, LL, pL, ablate);
+    MP(6)
+    // dictionary (compress.go:460-466): every lane searches on its own.  (Sharing the search between the lanes of a
+    // wave - their lower bounds are monotone in rank - was measured slower: the phases serialise the probe latency
+    // and a divergent probe loop costs the same issue slots however few lanes run it.)
+    int Ld = 0, pd = -1;
+    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, ablate);
+    MP(7)
+    MP_PRINT
+    if (!work) return;
+    res[sg.off + i] = select_backref(D, i, minD, dynOK, Ls, ps, LL, pL, Ld, pd);
 }
 
 // positions i < HEAD: brute force over the window [0, i) (identical for both window sizes there)
@@ -558,7 +602,9 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
     }
     const int Ls = best, ps = bp;
     const int LL = (dynOK && best >= minD) ? best : 0, pL = bp;
-    res[sg.off + i] = select_backref(D, T, i, maxLen, minD, dynOK, Ls, ps, LL, pL);
+    int Ld = 0, pd = -1;
+    if (dynOK && LL < maxLen) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, 0);  // compress.go:460
+    res[sg.off + i] = select_backref(D, i, minD, dynOK, Ls, ps, LL, pL, Ld, pd);
 }
 
 void launch_match_head(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
@@ -578,3 +624,14 @@ void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const Batc
 }
 
 }  // namespace lzss
+
+#ifdef MATCH_PROFILE
+extern "C" int mi355_lzss_debug_match_profile(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lzss::g_mp), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lzss::g_mp), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

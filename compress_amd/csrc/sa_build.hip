@@ -343,6 +343,15 @@ constexpr int SA_INIT_SYMS = 4;  // depth of the initial sort (symbols compared 
 #ifndef SA_USE_MTAB
 #define SA_USE_MTAB 1
 #endif
+#ifdef SA_PROFILE  // per-phase clocks of workgroup 0 (debug builds only)
+#define SA_PROF_DECL long long prof_acc[20] = {}; long long prof_last = clock64();
+#define SA_PROF(i) { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); prof_acc[i] += t_ - prof_last; prof_last = t_; }
+#define SA_PROF_PRINT if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x / 64 < 2) { printf("w%d init: ld %lld rank %lld prep %lld put %lld | regI %lld | S1: ld %lld gath %lld rank %lld prep %lld put %lld | S2: ld %lld rank %lld prep %lld put %lld | D %lld | other %lld\n", threadIdx.x / 64, prof_acc[0], prof_acc[1], prof_acc[2], prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11], prof_acc[12], prof_acc[13], prof_acc[14], prof_acc[15]); }
+#else
+#define SA_PROF_DECL
+#define SA_PROF(i)
+#define SA_PROF_PRINT
+#endif
 constexpr bool SA_MTAB = SA_USE_MTAB;    // lanes with equal digits find each other through a bit table in LDS
 constexpr bool SA_STAGE = SA_USE_STAGE;  // reorder every tile in LDS so that the scatter writes runs of records
 constexpr int SAM_THREADS = SA_MAIN_THREADS;
@@ -431,15 +440,14 @@ __device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lan
         }
     }
     if (__ballot(todo)) {
+        // the LDS unit executes one wave's instructions in order, so the three accesses need no waits between
+        // them; the empty asm statements only keep the compiler from reordering them
         if (todo) atomicOr((unsigned long long *)&mrow[d], 1ull << lane);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (todo) peers = mrow[d];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        if (todo) peers = *(volatile uint64_t *)&mrow[d];
+        asm volatile("" ::: "memory");
         if (todo) mrow[d] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
     }
     return peers;
 }
@@ -599,22 +607,28 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
         }
         int gKl[SA_K], gSl[SA_K];
         int runK = -1, runS = -1;
+        uint64_t bS[SA_K];
+#pragma unroll
+        for (int s = 0; s < SA_K; ++s) bS[s] = __ballot(fl[s] & 2);
+        const uint64_t lem = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
 #pragma unroll
         for (int s = 0; s < SA_K; ++s) {
             const uint32_t u = wb + s * 64 + lane;
-            int nf = __shfl_down(fl[s], 1) & 2;
-            const int nf0 = __shfl(fl[s + 1 < SA_K ? s + 1 : s], 0) & 2;  // executed by all lanes
-            if (lane == 63) nf = (s + 1 < SA_K) ? nf0 : ((un < m) ? (int)(nkey != key[s]) : 1);
-            if (u + 1 >= m) nf = 1;
+            // does the next entry start a run?  (from the ballots; the wave's last entry looks at its neighbour)
+            bool nf;
+            if (lane < 63) nf = (bS[s] >> (lane + 1)) & 1;
+            else if (s + 1 < SA_K) nf = bS[s + 1 < SA_K ? s + 1 : s] & 1;
+            else nf = (un < m) ? (nkey != key[s]) : true;
+            if (u + 1 >= m) nf = true;
             if ((fl[s] & 2) && nf) fl[s] |= 4;
-            int gK = wave_incl_max((fl[s] & 1) ? (int)u : -1, lane);
-            int gS = wave_incl_max((fl[s] & 2) ? (int)u : -1, lane);
-            gK = max(gK, runK);
-            gS = max(gS, runS);
-            runK = __shfl(gK, 63);
-            runS = __shfl(gS, 63);
-            gKl[s] = gK;
-            gSl[s] = gS;
+            // index of the last marked entry at or before this one: from the ballots, no scans
+            const int u0 = (int)(wb + s * 64);
+            const uint64_t bK = __ballot(fl[s] & 1);
+            const uint64_t lK = bK & lem, lS = bS[s] & lem;
+            gKl[s] = lK ? u0 + 63 - (int)__builtin_clzll(lK) : runK;
+            gSl[s] = lS ? u0 + 63 - (int)__builtin_clzll(lS) : runS;
+            if (bK) runK = u0 + 63 - (int)__builtin_clzll(bK);
+            if (bS[s]) runS = u0 + 63 - (int)__builtin_clzll(bS[s]);
         }
         if (lane == 0) {
             cy.a[par][w] = runK;
@@ -695,6 +709,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     const SaLds<DB> L(dyn_lds, words);
     uint64_t *recA = wk.recA + sg.off, *recB = wk.recB + sg.off;
 
+    SA_PROF_DECL
     for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;
     for (int x = tid; x < 5 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh
     for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
@@ -735,6 +750,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             }
             __syncthreads();
             bins_scan(L.hh, L.base, NB, tid);
+            SA_PROF(15)
             for (uint32_t t0 = 0; t0 < N; t0 += SA_TILE) {
                 const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
                 uint64_t r[SA_K];
@@ -745,12 +761,15 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     r[s] = 0;
                     if (e < N) r[s] = rin ? rin[e] : ((init_key(T, n, e) << 20) | (uint64_t)e);
                 }
+                SA_PROF(0)
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     const uint32_t e = wb + s * 64 + lane;
                     loc[s] = tile_rank<9, DB>(L, w, (int)(r[s] >> shift) & 511, e < N, lane);
                 }
+                SA_PROF(1)
                 const int tile_n = tile_prepare<DB>(L, tid);
+                SA_PROF(2)
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     const uint32_t e = wb + s * 64 + lane;
@@ -758,6 +777,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     if (e < N) tile_put<DB>(L, rout, sym, w * NB, loc[s], r[s]);
                 }
                 tile_flush<DB>(L, rout, shift, 511, tile_n, tid);
+                SA_PROF(3)
             }
             __syncthreads();
             rin = rout;
@@ -768,11 +788,14 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh
     __syncthreads();
 
+    SA_PROF(15)
     uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid);
+    SA_PROF(4)
     uint32_t h = (uint32_t)SA_INIT_SYMS;
     while (m != 0 && h < N && --max_rounds >= 0) {
         // ---- S1: active members of the sequence p = SA[j] - h -> records, scattered by the low digit of k1
         bins_scan(L.hl, L.base, NB, tid);
+        SA_PROF(15)
         {
             int tileG = 0;  // slot 0 always starts a group
             int par = 0;
@@ -784,6 +807,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     const uint32_t j = wb + s * 64 + lane;
                     sv[s] = (j < N) ? sa[j] : 0;
                 }
+                SA_PROF(5)
                 int p[SA_K], k1[SA_K], k2[SA_K], loc[SA_K];
                 bool a[SA_K];
 #pragma unroll
@@ -795,6 +819,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     a[s] = (j < N) && ((L.act[pp >> 5] >> (pp & 31)) & 1u);
                     k1[s] = a[s] ? rk[pp] : 0;
                 }
+                SA_PROF(6)
                 int runG = -1;
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
@@ -811,7 +836,9 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     if (__ballot(a[s])) loc[s] = tile_rank<DB, DB>(L, w, k1[s] & MASK, a[s], lane);
                 }
                 if (lane == 0) cy.a[par][w] = runG;
+                SA_PROF(7)
                 const int tile_n = tile_prepare<DB>(L, tid);
+                SA_PROF(8)
                 int cin = tileG;
                 for (int ww = 0; ww < SAM_WAVES; ++ww) {
                     const int g = cy.a[par][ww];
@@ -828,12 +855,14 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     }
                 }
                 tile_flush<DB>(L, recA, 40, MASK, tile_n, tid);
+                SA_PROF(9)
             }
         }
         __syncthreads();
         // ---- S2: records by the high digit of k1
         bins_scan(L.hh, L.base, NB, tid);
         for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh: refilled by the regroup below
+        SA_PROF(15)
         for (uint32_t t0 = 0; t0 < m; t0 += SA_TILE) {
             const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
             uint64_t r[SA_K];
@@ -843,12 +872,15 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                 const uint32_t u = wb + s * 64 + lane;
                 r[s] = (u < m) ? recA[u] : 0;
             }
+            SA_PROF(10)
 #pragma unroll
             for (int s = 0; s < SA_K; ++s) {
                 const uint32_t u = wb + s * 64 + lane;
                 loc[s] = tile_rank<DB, DB>(L, w, (int)(r[s] >> (40 + DB)) & MASK, u < m, lane);
             }
+            SA_PROF(11)
             const int tile_n = tile_prepare<DB>(L, tid);
+            SA_PROF(12)
 #pragma unroll
             for (int s = 0; s < SA_K; ++s) {
                 const uint32_t u = wb + s * 64 + lane;
@@ -856,16 +888,21 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                 if (u < m) tile_put<DB>(L, recB, d, w * NB, loc[s], r[s]);
             }
             tile_flush<DB>(L, recB, 40 + DB, MASK, tile_n, tid);
+            SA_PROF(13)
         }
         __syncthreads();
+        SA_PROF(15)
         // ---- D: new groups
         m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid);
+        SA_PROF(14)
         h *= 2;
     }
     if (m != 0) {  // rounds cut short (timing experiments): drop the group marks so that SA stays a permutation
         __syncthreads();
         for (uint32_t j = tid; j < N; j += SAM_THREADS) sa[j] &= 0x7FFFFFFF;
     }
+    SA_PROF(15)
+    SA_PROF_PRINT
 }
 
 // ---- window index: ranks regrouped by the 16 KiB chunk of their position (stable in rank order) ------
@@ -907,11 +944,15 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
     }
     __syncthreads();
     int32_t *hrow = sh.hist[w];
+    uint16_t *cdir = ix.cdir + (sg.off / 64) * ix.nch;
     for (uint32_t k0 = cbeg; k0 < cend; k0 += 64) {
         const uint32_t k = k0 + lane;
         const bool active = k < cend;
         const int p = active ? SA[k] : 0;
         const int c = p >> WIN_SHIFT;
+        // directory: entries of every chunk before rank k0 (k0 == 1 + 64 b; the waves' rank ranges are whole blocks)
+        for (int cc = lane; cc < nch; cc += 64) cdir[((k0 - 1) >> 6) * ix.nch + cc] = (uint16_t)(hrow[cc] - (cc << WIN_SHIFT));
+        __builtin_amdgcn_wave_barrier();
         const uint64_t amask = __ballot(active);
         const uint64_t peers = match_digit(c, amask);
         const int cnt = __popcll(peers);
