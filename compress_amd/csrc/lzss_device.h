@@ -72,6 +72,13 @@ struct IndexView {
     const uint16_t *bmin2;  // min of bmin1 over blocks of 64 blocks
 };
 
+// XCD-aware block order.  Blocks b and b + 8 of a launch land on the same XCD (MI355X_MICROARCH.md, workgroup
+// dispatch), each XCD has its own 4 MiB L2, and the index arrays of one 128 KiB segment are ~2.5 MB.  Launching a
+// 1-D grid of nblk (multiple of 8) blocks and working on virtual block (b % 8) * (nblk / 8) + b / 8 lets every XCD
+// walk a contiguous eighth of the (segment, block) space, so a segment's random accesses meet in ONE L2.
+__device__ inline uint32_t xcd_block(uint32_t b, uint32_t nblk) { return (b & 7u) * (nblk >> 3) + (b >> 3); }
+inline uint32_t xcd_grid(uint64_t blocks) { return (uint32_t)((blocks + 7) / 8 * 8); }
+
 // 8 bytes at any byte address (amdhsa runs with unaligned access enabled)
 __device__ inline uint64_t ld8(const uint8_t *p) {
     uint64_t v;

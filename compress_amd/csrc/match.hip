@@ -27,6 +27,20 @@
 
 namespace lzss {
 
+#ifdef MATCH_PROFILE  // per-section clocks summed over all waves (debug builds only)
+__device__ unsigned long long g_mp[16];
+#define MP_DECL long long mp_acc[15] = {}; long long mp_last = clock64();
+#define MP(i) { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); mp_acc[i] += t_ - mp_last; mp_last = t_; }
+#define MP_PRINT if (threadIdx.x == 0 && (blockIdx.x & 31) == 0) { for (int q_ = 0; q_ < 15; ++q_) atomicAdd(&g_mp[q_], (unsigned long long)mp_acc[q_]); atomicAdd(&g_mp[15], 1ull); }
+#define MP_ARG , long long *mp_acc, long long &mp_last
+#define MP_PASS , mp_acc, mp_last
+#else
+#define MP_DECL
+#define MP(i)
+#define MP_PRINT
+#define MP_ARG
+#define MP_PASS
+#endif
 constexpr int LCP_THREADS = 256;
 constexpr int MATCH_THREADS = 256;
 
@@ -289,14 +303,18 @@ __device__ inline int chunk_lower_bound(const int32_t *KS, int a, int end, int l
 
 // Smallest-rank occurrence inside the SHORT window [ws, i) among the suffixes sharing >= L bytes with
 // rank kdn (which is itself in the window, so the answer is <= kdn).
-__device__ inline int leftmost_short(const SegIndex &S, int kdn, int L, int ws, int i) {
+__device__ inline int leftmost_short(const SegIndex &S, int kdn, int L, int ws, int i MP_ARG) {
     const int lo = prev_lower(S.LCP, S.b1, S.b2, kdn, L);
+    MP(8)
     if (kdn - lo <= LINEAR_SPAN) {
-        for (int k = lo; k < kdn; ++k) {
+        int res = -1;
+        for (int k = lo; k < kdn && res < 0; ++k) {
             const int p = S.SA[k];
-            if (p >= ws && p < i) return p;
+            if (p >= ws && p < i) res = p;
         }
-        return S.SA[kdn];
+        if (res < 0) res = S.SA[kdn];
+        MP(9)
+        return res;
     }
     int best = kdn;
     const int c2 = (i - 1) >> LZSS_SHORT_ADDR_BITS;  // chunk of the window's last position: entries with pos < i
@@ -306,32 +324,43 @@ __device__ inline int leftmost_short(const SegIndex &S, int kdn, int L, int ws, 
         const int beg = c2 << LZSS_SHORT_ADDR_BITS;
         const int end = (beg + LZSS_SHORT_WINDOW) < S.n ? (beg + LZSS_SHORT_WINDOW) : S.n;
         const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2], end, lo1);
+        MP(10)
         const int j = next_thr<true>(S.PS, S.pmin1, S.pmin2, a, end, i);
         if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
+        MP(11)
     }
     if (c2 >= 1 && ws < (c2 << LZSS_SHORT_ADDR_BITS)) {  // previous chunk: entries with pos >= ws
         const int beg = (c2 - 1) << LZSS_SHORT_ADDR_BITS;
         const int end = beg + LZSS_SHORT_WINDOW;
         const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2 - 1], end, lo1);
+        MP(10)
         const int j = next_thr<false>(S.PS, S.pmax1, S.pmax2, a, end, ws);
         if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
+        MP(11)
     }
-    return S.SA[best];
+    const int res = S.SA[best];
+    MP(11)
+    return res;
 }
 
 // the same for the LONG window [ws, i); ws == 0 whenever i <= 2^21, and then "pos < i" over the suffix
 // array itself is a one-sided condition
-__device__ inline int leftmost_long(const SegIndex &S, int kdn, int L, int ws, int i) {
+__device__ inline int leftmost_long(const SegIndex &S, int kdn, int L, int ws, int i MP_ARG) {
     const int lo = prev_lower(S.LCP, S.b1, S.b2, kdn, L);
+    MP(12)
+    int res = -1;
     if (ws == 0 && kdn - lo > LINEAR_SPAN) {
         const int k = next_thr<true>(S.SA, S.samin1, S.samin2, lo, kdn + 1, i);
-        return S.SA[k <= kdn ? k : kdn];
+        res = S.SA[k <= kdn ? k : kdn];
+    } else {
+        for (int k = lo; k < kdn && res < 0; ++k) {
+            const int p = S.SA[k];
+            if (p >= ws && p < i) res = p;
+        }
+        if (res < 0) res = S.SA[kdn];
     }
-    for (int k = lo; k < kdn; ++k) {
-        const int p = S.SA[k];
-        if (p >= ws && p < i) return p;
-    }
-    return S.SA[kdn];
+    MP(13)
+    return res;
 }
 
 // true when the walk can never call bestBackref(i): i, i-1 and i-2 lie in one run of equal bytes and at
@@ -346,16 +375,6 @@ __device__ inline bool never_queried(const uint8_t *T, int n, int i) {
     return true;
 }
 
-#ifdef MATCH_PROFILE  // per-section clocks summed over all waves (debug builds only)
-__device__ unsigned long long g_mp[16];
-#define MP_DECL long long mp_acc[10] = {}; long long mp_last = clock64();
-#define MP(i) { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); mp_acc[i] += t_ - mp_last; mp_last = t_; }
-#define MP_PRINT if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_mp[q_], (unsigned long long)mp_acc[q_]); atomicAdd(&g_mp[8], 1ull); }
-#else
-#define MP_DECL
-#define MP(i)
-#define MP_PRINT
-#endif
 constexpr int SCAN_CAP = 8;  // x4 ranks a lane walks alone before its wave takes the walk over
 
 __device__ inline int wave_incl_min(int v, int lane) {
@@ -370,14 +389,17 @@ __device__ inline int wave_incl_min(int v, int lane) {
 // One lane per rank.  The walks to the nearest in-window neighbours are short for most ranks and very long
 // for a few (heavy tail), so a lane walks SCAN_CAP x 4 ranks alone; whatever is left is finished by the
 // whole wave, 64 ranks per step (coalesced loads, prefix-min of LCP across lanes, ballot for the first hit).
-__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, BatchIndex ix, DictView D, uint32_t *res,
-                                                              int skip_unqueried, int ablate) {
-    const Seg sg = segs[blockIdx.y];
+__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, BatchIndex ix,
+                                                              DictView D, uint32_t *res, int skip_unqueried, int ablate) {
+    const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);
+    if (vb >= gx * n_segs) return;
+    const uint32_t bx = vb % gx;
+    const Seg sg = segs[vb / gx];
     const int n = (int)sg.n;
     const int N = n + 1;
-    if ((int)(blockIdx.x * MATCH_THREADS) >= N) return;
+    if ((int)(bx * MATCH_THREADS) >= N) return;
     const int lane = threadIdx.x & 63;
-    const int r = (int)(blockIdx.x * MATCH_THREADS + threadIdx.x);
+    const int r = (int)(bx * MATCH_THREADS + threadIdx.x);
     MP_DECL
     const uint8_t *T = ix.text + sg.off;
     const int32_t *SA = ix.sa + sg.off;
@@ -554,7 +576,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
     if (work) {
         const int ld = LdnS >= minS ? LdnS : 0, lu = LupS >= minS ? LupS : 0;
         Ls = ld > lu ? ld : lu;
-        if (Ls > 0) ps = (lu > ld) ? pupS : ((ablate & 2) ? SA[kdnS] : leftmost_short(S, kdnS, Ls, wsS, i));
+        if (Ls > 0) ps = (lu > ld) ? pupS : ((ablate & 2) ? SA[kdnS] : leftmost_short(S, kdnS, Ls, wsS, i MP_PASS));
     }
     MP(5)
     // long window
@@ -562,7 +584,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, B
     if (work && dynOK) {
         const int ld = LdnL >= minD ? LdnL : 0, lu = LupL >= minD ? LupL : 0;
         LL = ld > lu ? ld : lu;
-        if (LL > 0) pL = (lu > ld) ? pupL : ((ablate & 2) ? SA[kdnL] : leftmost_long(S, kdnL, LL, wsL, i));
+        if (LL > 0) pL = (lu > ld) ? pupL : ((ablate & 2) ? SA[kdnL] : leftmost_long(S, kdnL, LL, wsL, i MP_PASS));
     }
     MP(6)
     // dictionary (compress.go:460-466): every lane searches on its own.  (Sharing the search between the lanes of a
@@ -619,8 +641,9 @@ void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const Batc
                   uint32_t *d_res, bool skip_unqueried, hipStream_t stream) {
     if (n_segs == 0 || max_n <= (uint32_t)HEAD) return;
     static const int ablate = getenv("MI355_LZSS_ABLATE") ? atoi(getenv("MI355_LZSS_ABLATE")) : 0;  // timing experiments only
-    dim3 g((max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS, n_segs);
-    hipLaunchKernelGGL(match_kernel, g, dim3(MATCH_THREADS), 0, stream, d_segs, ix, dict, d_res, skip_unqueried ? 1 : 0, ablate);
+    const uint32_t gx = (max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS;  // blocks per segment
+    hipLaunchKernelGGL(match_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(MATCH_THREADS), 0, stream, d_segs, n_segs, gx,
+                       ix, dict, d_res, skip_unqueried ? 1 : 0, ablate);
 }
 
 }  // namespace lzss

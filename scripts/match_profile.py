@@ -17,8 +17,8 @@ buf = (C.c_ulonglong * 16)()
 f(buf, 1)
 bt.compress()
 f(buf, 1)
-names = ["setup", "up", "coopup", "dn", "coopdn", "lshort", "llong", "dict"]
-tot = sum(buf[:8])
+names = ["setup", "up", "coopup", "dn", "coopdn", "lshort_rest", "llong_rest", "dict", "S:prev_lower", "S:linear", "S:chunk_lb", "S:next_thr", "L:prev_lower", "L:rest", "-"]
+tot = sum(buf[:15])
 for k, nm in enumerate(names):
-    print("%-8s %6.1f%%  %10.0f cycles/wave" % (nm, 100.0 * buf[k] / tot, buf[k] / max(buf[8], 1)))
-print("waves", buf[8], "stages", bt.stage_times() if hasattr(bt, "stage_times") else "")
+    print("%-8s %6.1f%%  %10.0f cycles/wave" % (nm, 100.0 * buf[k] / tot, buf[k] / max(buf[15], 1)))
+print("waves", buf[15], "stages", bt.stage_times() if hasattr(bt, "stage_times") else "")
