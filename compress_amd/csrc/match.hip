@@ -433,22 +433,35 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     // ---- nearest in-window neighbours above r (the arrays are padded past N)
     {
         int m = 1 << 20, k = r + 1;
-        bool fL = false, done = !scan;
-        for (int it = 0; it < SCAN_CAP && !done && k < N; ++it, k += 4) {
-            const I4 sa4 = ld_i4(SA + k);
-            const U4 l4 = ld_u4(LCP + k);
+        bool fL = false, done = !scan || k >= N;
+        // written with selects, not branches: the scalar unit (exec-mask bookkeeping) is this kernel's scarcest resource
+        for (int it = 0; it < SCAN_CAP && __ballot(!done); ++it) {
+            I4 sa4;
+            U4 l4;
+            sa4.v = 0x7FFFFFFF;
+            l4.v = 0;
+            if (!done) {
+                sa4 = ld_i4(SA + k);
+                l4 = ld_u4(LCP + k);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (done || k + t >= N) { done = true; continue; }
                 const int l = l4.v[t];
-                m = l < m ? l : m;
-                if (m < minS) { done = true; continue; }
+                const int mm = l < m ? l : m;
+                const bool live = !done && (k + t < N);
                 const int p = sa4.v[t];
-                if (p < i) {
-                    if (!fL && p >= wsL) { fL = true; LupL = m; pupL = p; }
-                    if (p >= wsS) { LupS = m; pupS = p; done = true; }
-                }
+                const bool cand = live && mm >= minS && p < i;
+                const bool hL = cand && !fL && p >= wsL;
+                const bool hS = cand && p >= wsS;
+                LupL = hL ? mm : LupL;
+                pupL = hL ? p : pupL;
+                fL = fL || hL;
+                LupS = hS ? mm : LupS;
+                pupS = hS ? p : pupS;
+                m = live ? mm : m;
+                done = done || !live || mm < minS || hS;
             }
+            k = done ? k : k + 4;
         }
         if (k >= N) done = true;
         MP(1)
@@ -492,24 +505,39 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     MP(2)
     // ---- nearest in-window neighbours below r: lcp(i, SA[k]) = min LCP[k+1 .. r]; rank 0 is the sentinel
     {
-        int m = 1 << 20, k = r - 1, it = 0;
+        int m = 1 << 20, k = r - 1;
         bool fL = false, done = !scan;
-        for (; k >= 4 && !done && it < SCAN_CAP; k -= 4, ++it) {  // ranks k, k-1, k-2, k-3
-            const I4 sa4 = ld_i4(SA + k - 3);
-            const U4 l4 = ld_u4(LCP + k - 2);
+        for (int it = 0; it < SCAN_CAP && __ballot(!done && k >= 4); ++it) {  // ranks k, k-1, k-2, k-3
+            const bool go = !done && k >= 4;
+            I4 sa4;
+            U4 l4;
+            sa4.v = 0x7FFFFFFF;
+            l4.v = 0;
+            if (go) {
+                sa4 = ld_i4(SA + k - 3);
+                l4 = ld_u4(LCP + k - 2);
+            }
+            bool stop = !go;
 #pragma unroll
             for (int t = 3; t >= 0; --t) {
-                if (done) continue;
                 const int l = l4.v[t];
-                m = l < m ? l : m;
-                if (m < minS) { done = true; continue; }
+                const int mm = l < m ? l : m;
+                const bool live = !stop;
                 const int p = sa4.v[t];
-                if (p < i) {
-                    const int kk = k - 3 + t;
-                    if (!fL && p >= wsL) { fL = true; LdnL = m; kdnL = kk; }
-                    if (p >= wsS) { LdnS = m; kdnS = kk; done = true; }
-                }
+                const bool cand = live && mm >= minS && p < i;
+                const bool hL = cand && !fL && p >= wsL;
+                const bool hS = cand && p >= wsS;
+                const int kk = k - 3 + t;
+                LdnL = hL ? mm : LdnL;
+                kdnL = hL ? kk : kdnL;
+                fL = fL || hL;
+                LdnS = hS ? mm : LdnS;
+                kdnS = hS ? kk : kdnS;
+                m = live ? mm : m;
+                stop = stop || mm < minS || hS;
             }
+            done = done || (go && stop);
+            k = (go && !stop) ? k - 4 : k;
         }
         if (!done && k < 4) {
             for (; k >= 1 && !done; --k) {

@@ -352,6 +352,13 @@ constexpr int SA_INIT_SYMS = 4;  // depth of the initial sort (symbols compared 
 #define SA_PROF(i)
 #define SA_PROF_PRINT
 #endif
+#ifndef SA_MTAB_BITS
+#define SA_MTAB_BITS 10
+#endif
+constexpr int SA_MTB = SA_MTAB_BITS;     // digit bits resolved by the table (the rest by ballots)
+#ifndef SA_WGS_PER_CU
+#define SA_WGS_PER_CU 2
+#endif
 constexpr bool SA_MTAB = SA_USE_MTAB;    // lanes with equal digits find each other through a bit table in LDS
 constexpr bool SA_STAGE = SA_USE_STAGE;  // reorder every tile in LDS so that the scatter writes runs of records
 constexpr int SAM_THREADS = SA_MAIN_THREADS;
@@ -383,16 +390,17 @@ __device__ inline uint64_t match_bits(int d, uint64_t amask) {
 template <int DB>
 struct SaLds {
     static constexpr int NB = 1 << DB;
+    static constexpr int mtab_entries() { return 1 << (DB < SA_MTB ? DB : SA_MTB); }
     uint32_t *act;     // bit p: suffix p still shares its group
     int32_t *base;     // [NB] running output index of bin b
     int32_t *delta;    // [NB] output index minus staging index for the tile's entries of bin b
     int32_t *tpos;     // [NB] staging index of the tile's first entry of bin b
     int32_t *hl, *hh;  // [NB] digit counts of the next round's keys (low / high digit)
     int32_t *wtot;     // [16] tile entries per wave of bin threads
-    uint16_t *whist;   // [SAM_WAVES][NB] entries of the current tile per wave and bin (zero between tiles)
-    uint16_t *woff;    // [SAM_WAVES][NB] offset of wave w's entries inside the tile's bin b
+    uint16_t *whist;   // [NB][SAM_WAVES] entries of the current tile per bin and wave (zero between tiles)
+    uint16_t *woff;    // [NB][SAM_WAVES] offset of wave w's entries inside the tile's bin b
     uint64_t *stage;   // [SA_TILE] the tile's records in bin order
-    uint64_t *mtab;    // [SAM_WAVES][NB] per wave: lanes holding digit d (zero between steps)
+    uint64_t *mtab;    // [SAM_WAVES][mtab_entries()] per wave: lanes holding (the low bits of) digit d (zero between steps)
     __device__ SaLds(uint32_t *mem, uint32_t words) {
         act = mem;
         base = (int32_t *)(act + words);
@@ -409,7 +417,7 @@ struct SaLds {
     // words: bitmap words (even)
     static size_t bytes(uint32_t words) {
         return (size_t)words * 4 + ((size_t)NB * 5 + 16) * 4 + (size_t)SAM_WAVES * NB * 4 + (SA_STAGE ? (size_t)SA_TILE * 8 : 0) +
-               (SA_MTAB ? (size_t)SAM_WAVES * NB * 8 : 0);
+               (SA_MTAB ? (size_t)SAM_WAVES * mtab_entries() * 8 : 0);
     }
 };
 
@@ -442,12 +450,20 @@ __device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lan
     if (__ballot(todo)) {
         // the LDS unit executes one wave's instructions in order, so the three accesses need no waits between
         // them; the empty asm statements only keep the compiler from reordering them
-        if (todo) atomicOr((unsigned long long *)&mrow[d], 1ull << lane);
+        constexpr int TB = RB < SA_MTB ? RB : SA_MTB;
+        uint64_t *cell = mrow + (d & ((1 << TB) - 1));
+        if (todo) atomicOr((unsigned long long *)cell, 1ull << lane);
         asm volatile("" ::: "memory");
-        if (todo) peers = *(volatile uint64_t *)&mrow[d];
+        if (todo) peers = *(volatile uint64_t *)cell;
         asm volatile("" ::: "memory");
-        if (todo) mrow[d] = 0;
+        if (todo) *cell = 0;
         asm volatile("" ::: "memory");
+#pragma unroll
+        for (int bit = TB; bit < RB; ++bit) {  // digit bits beyond the table: ballots
+            const bool b = (d >> bit) & 1;
+            const uint64_t bal = __ballot(b);
+            peers &= b ? bal : ~bal;
+        }
     }
     return peers;
 }
@@ -455,13 +471,13 @@ __device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lan
 // rank of this lane's entry among the entries of its wave's tile part with the same digit (stable)
 template <int RB, int DB>
 __device__ inline int tile_rank(const SaLds<DB> &L, int w, int d, bool valid, int lane) {
-    uint16_t *wrow = L.whist + w * (1 << DB);
-    const uint64_t peers = wave_peers<RB>(L.mtab + w * (1 << DB), d, valid, lane);
+    uint16_t *cell = L.whist + d * SAM_WAVES + w;
+    const uint64_t peers = wave_peers<RB>(L.mtab + w * SaLds<DB>::mtab_entries(), d, valid, lane);
     const int cnt = __popcll(peers);
     const int rank = __popcll(peers & lanemask_lt(lane));
-    const int lh = valid ? (int)wrow[d] : 0;
+    const int lh = valid ? (int)*cell : 0;
     __builtin_amdgcn_wave_barrier();
-    if (valid && rank == cnt - 1) wrow[d] = (uint16_t)(lh + cnt);
+    if (valid && rank == cnt - 1) *cell = (uint16_t)(lh + cnt);
     __builtin_amdgcn_wave_barrier();
     return lh + rank;
 }
@@ -484,14 +500,19 @@ __device__ inline int tile_prepare(const SaLds<DB> &L, int tid) {
         gs[i] = 0;
         if (tid < NBT) {
             const int b = tid * BPT + i;
+            // the bin's counts of all waves in one load, their running sums in one store
+            typedef uint16_t u16xw_t __attribute__((ext_vector_type(SAM_WAVES)));
+            u16xw_t *hp = reinterpret_cast<u16xw_t *>(L.whist + b * SAM_WAVES);
+            const u16xw_t cnts = *hp;
+            u16xw_t offs;
             int r = 0;
 #pragma unroll
             for (int ww = 0; ww < SAM_WAVES; ++ww) {
-                const int t = L.whist[ww * NB + b];
-                L.whist[ww * NB + b] = 0;
-                L.woff[ww * NB + b] = (uint16_t)r;
-                r += t;
+                offs[ww] = (uint16_t)r;
+                r += (int)cnts[ww];
             }
+            *hp = (u16xw_t)(uint16_t)0;
+            *reinterpret_cast<u16xw_t *>(L.woff + b * SAM_WAVES) = offs;
             run[i] = r;
             gs[i] = L.base[b];
             L.base[b] = gs[i] + r;
@@ -524,8 +545,8 @@ __device__ inline int tile_prepare(const SaLds<DB> &L, int tid) {
 
 // one record of the tile: to its staging position, or straight to the output
 template <int DB>
-__device__ inline void tile_put(const SaLds<DB> &L, uint64_t *out, int d, int wrow_off, int loc, uint64_t r) {
-    const int pos = L.tpos[d] + (int)L.woff[wrow_off + d] + loc;
+__device__ inline void tile_put(const SaLds<DB> &L, uint64_t *out, int d, int w, int loc, uint64_t r) {
+    const int pos = L.tpos[d] + (int)L.woff[d * SAM_WAVES + w] + loc;
     if (SA_STAGE) L.stage[pos] = r;
     else out[L.delta[d] + pos] = r;
 }
@@ -686,7 +707,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
 }
 
 template <int DB>
-__global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM_WAVES / 2, SAM_WAVES / 2))) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
+__global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM_WAVES * SA_WGS_PER_CU / 4, SAM_WAVES * SA_WGS_PER_CU / 4))) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
     constexpr int NB = 1 << DB;
     constexpr int MASK = NB - 1;
     __shared__ SaCarry cy;
@@ -714,7 +735,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     for (int x = tid; x < 5 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh
     for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
     if (SA_MTAB)
-        for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.mtab[x] = 0;
+        for (int x = tid; x < SAM_WAVES * SaLds<DB>::mtab_entries(); x += SAM_THREADS) L.mtab[x] = 0;
     __syncthreads();
 
     // ---- byte histogram of the text (hl[c] = occurrences of byte c)
@@ -751,16 +772,20 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             __syncthreads();
             bins_scan(L.hh, L.base, NB, tid);
             SA_PROF(15)
+            // the records of the next tile are loaded while the current one is being placed
+            auto load_rec = [&](uint32_t e) -> uint64_t {
+                if (e >= N) return 0;
+                return rin ? rin[e] : ((init_key(T, n, e) << 20) | (uint64_t)e);
+            };
+            uint64_t nx[SA_K];
+#pragma unroll
+            for (int s = 0; s < SA_K; ++s) nx[s] = load_rec((uint32_t)w * SA_WSPAN + s * 64 + lane);
             for (uint32_t t0 = 0; t0 < N; t0 += SA_TILE) {
                 const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
                 uint64_t r[SA_K];
                 int loc[SA_K];
 #pragma unroll
-                for (int s = 0; s < SA_K; ++s) {
-                    const uint32_t e = wb + s * 64 + lane;
-                    r[s] = 0;
-                    if (e < N) r[s] = rin ? rin[e] : ((init_key(T, n, e) << 20) | (uint64_t)e);
-                }
+                for (int s = 0; s < SA_K; ++s) r[s] = nx[s];
                 SA_PROF(0)
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
@@ -768,13 +793,17 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     loc[s] = tile_rank<9, DB>(L, w, (int)(r[s] >> shift) & 511, e < N, lane);
                 }
                 SA_PROF(1)
+                if (t0 + SA_TILE < N) {
+#pragma unroll
+                    for (int s = 0; s < SA_K; ++s) nx[s] = load_rec(wb + SA_TILE + s * 64 + lane);
+                }
                 const int tile_n = tile_prepare<DB>(L, tid);
                 SA_PROF(2)
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
                     const uint32_t e = wb + s * 64 + lane;
                     const int sym = (int)(r[s] >> shift) & 511;
-                    if (e < N) tile_put<DB>(L, rout, sym, w * NB, loc[s], r[s]);
+                    if (e < N) tile_put<DB>(L, rout, sym, w, loc[s], r[s]);
                 }
                 tile_flush<DB>(L, rout, shift, 511, tile_n, tid);
                 SA_PROF(3)
@@ -799,14 +828,17 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         {
             int tileG = 0;  // slot 0 always starts a group
             int par = 0;
+            int nsv[SA_K];
+#pragma unroll
+            for (int s = 0; s < SA_K; ++s) {
+                const uint32_t j = (uint32_t)w * SA_WSPAN + s * 64 + lane;
+                nsv[s] = (j < N) ? sa[j] : 0;
+            }
             for (uint32_t t0 = 0; t0 < N; t0 += SA_TILE, par ^= 1) {
                 const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
                 int sv[SA_K];
 #pragma unroll
-                for (int s = 0; s < SA_K; ++s) {
-                    const uint32_t j = wb + s * 64 + lane;
-                    sv[s] = (j < N) ? sa[j] : 0;
-                }
+                for (int s = 0; s < SA_K; ++s) sv[s] = nsv[s];
                 SA_PROF(5)
                 int p[SA_K], k1[SA_K], k2[SA_K], loc[SA_K];
                 bool a[SA_K];
@@ -818,6 +850,13 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     p[s] = (int)pp;
                     a[s] = (j < N) && ((L.act[pp >> 5] >> (pp & 31)) & 1u);
                     k1[s] = a[s] ? rk[pp] : 0;
+                }
+                if (t0 + SA_TILE < N) {  // the next tile's slots, loaded while this tile is being placed
+#pragma unroll
+                    for (int s = 0; s < SA_K; ++s) {
+                        const uint32_t j = wb + SA_TILE + s * 64 + lane;
+                        nsv[s] = (j < N) ? sa[j] : 0;
+                    }
                 }
                 SA_PROF(6)
                 int runG = -1;
@@ -850,7 +889,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     if (a[s]) {
                         const int d = k1[s] & MASK;
                         const int g = k2[s] < 0 ? cin : k2[s];
-                        tile_put<DB>(L, recA, d, w * NB, loc[s],
+                        tile_put<DB>(L, recA, d, w, loc[s],
                                      ((uint64_t)(uint32_t)k1[s] << 40) | ((uint64_t)(uint32_t)g << 20) | (uint64_t)(uint32_t)p[s]);
                     }
                 }
@@ -885,7 +924,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             for (int s = 0; s < SA_K; ++s) {
                 const uint32_t u = wb + s * 64 + lane;
                 const int d = (int)(r[s] >> (40 + DB)) & MASK;
-                if (u < m) tile_put<DB>(L, recB, d, w * NB, loc[s], r[s]);
+                if (u < m) tile_put<DB>(L, recB, d, w, loc[s], r[s]);
             }
             tile_flush<DB>(L, recB, 40 + DB, MASK, tile_n, tid);
             SA_PROF(13)
