@@ -42,7 +42,10 @@ __device__ unsigned long long g_mp[16];
 #define MP_PASS
 #endif
 constexpr int LCP_THREADS = 256;
-constexpr int MATCH_THREADS = 256;
+#ifndef MATCH_BLOCK
+#define MATCH_BLOCK 64
+#endif
+constexpr int MATCH_THREADS = MATCH_BLOCK;
 
 // ---- LCP array and its block minima -------------------------------------------------------------
 __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, BatchIndex ix) {
@@ -282,7 +285,10 @@ struct SegIndex {  // one segment's view of BatchIndex
     int n;
 };
 
-constexpr int LINEAR_SPAN = 24;  // intervals up to this many ranks are scanned directly
+#ifndef MATCH_LINEAR_SPAN
+#define MATCH_LINEAR_SPAN 24
+#endif
+constexpr int LINEAR_SPAN = MATCH_LINEAR_SPAN;  // intervals up to this many ranks are scanned directly
 
 // first entry j in [a, end) of a chunk's rank-ordered list with KS[j] >= lo, a coming from the chunk directory
 // (so at most 64 entries away, a chunk's share of 64 ranks)
@@ -375,7 +381,10 @@ __device__ inline bool never_queried(const uint8_t *T, int n, int i) {
     return true;
 }
 
-constexpr int SCAN_CAP = 8;  // x4 ranks a lane walks alone before its wave takes the walk over
+#ifndef MATCH_SCAN_CAP
+#define MATCH_SCAN_CAP 8
+#endif
+constexpr int SCAN_CAP = MATCH_SCAN_CAP;  // x4 ranks a lane walks alone before its wave takes the walk over
 
 __device__ inline int wave_incl_min(int v, int lane) {
 #pragma unroll
