@@ -1,0 +1,33 @@
+#!/bin/bash
+# usage (GPU box): scripts/profile_round.sh TAG   -> gpurun_out/TAG_{bench.json,kernel_stats.csv,pmc_hbm_traffic.csv}
+# One bench run for the JSON line, one rocprofv3 --kernel-trace --stats run, two --pmc runs (FETCH_SIZE, WRITE_SIZE).
+tag=$1
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 python3 $root/bench.py --steps 5 --warmup 1 > $out/${tag}_bench.log 2>&1 || { echo "bench failed"; tail -5 $out/${tag}_bench.log; exit 1; }
+tail -1 $out/${tag}_bench.log > $out/${tag}_bench.json
+rm -rf $out/${tag}_trace
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o t --output-format csv -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu > $out/${tag}_trace.log 2>&1 || { echo "trace failed"; exit 1; }
+cp $(find $out/${tag}_trace -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $out/${tag}_pmc_$c
+  timeout -s KILL 200 rocprofv3 --pmc $c -d $out/${tag}_pmc_$c -o p --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu > $out/${tag}_pmc_$c.log 2>&1 || { echo "pmc $c failed"; exit 1; }
+done
+python3 - "$out" "$tag" <<'PY'
+import sys,csv,glob,collections,re
+out,tag=sys.argv[1],sys.argv[2]
+rows=[]
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    f=glob.glob(f"{out}/{tag}_pmc_{c}/**/*counter_collection.csv",recursive=True)
+    agg=collections.defaultdict(float); disp=collections.defaultdict(set)
+    for r in csv.DictReader(open(f[0])):
+        if r['Counter_Name']!=c: continue
+        k=re.sub(r"\(.*","",r['Kernel_Name'])
+        agg[k]+=float(r['Counter_Value']); disp[k].add(r['Dispatch_Id'])
+    for k in sorted(agg): rows.append((k,c,int(agg[k]),len(disp[k])))
+with open(f"{out}/{tag}_pmc_hbm_traffic.csv","w") as g:
+    g.write("kernel,counter,sum_value_KB,dispatches\n")
+    for r in rows: g.write("%s,%s,%d,%d\n"%r)
+print("ok", len(rows))
+PY
