@@ -307,65 +307,48 @@ __device__ inline int chunk_lower_bound(const int32_t *KS, int a, int end, int l
     return end;
 }
 
-// Smallest-rank occurrence inside the SHORT window [ws, i) among the suffixes sharing >= L bytes with
-// rank kdn (which is itself in the window, so the answer is <= kdn).
-__device__ inline int leftmost_short(const SegIndex &S, int kdn, int L, int ws, int i MP_ARG) {
+// Smallest-rank occurrence inside the window [ws, i) among the suffixes sharing >= L bytes with rank kdn (which is
+// itself in the window, so the answer is <= kdn).  SHORT window: through the window index (two chunks, one-sided
+// condition in each).  LONG window: ws == 0 whenever i <= 2^21, and then "pos < i" over the suffix array itself is
+// one-sided.  A lane needs this for ONE of its two windows only (the one whose reference is emitted), so both share
+// the interval search.
+__device__ inline int leftmost(const SegIndex &S, int kdn, int L, int ws, int i, bool is_short MP_ARG) {
     const int lo = prev_lower(S.LCP, S.b1, S.b2, kdn, L);
     MP(8)
-    if (kdn - lo <= LINEAR_SPAN) {
-        int res = -1;
+    int res = -1;
+    if (kdn - lo <= LINEAR_SPAN || (!is_short && ws != 0)) {
         for (int k = lo; k < kdn && res < 0; ++k) {
             const int p = S.SA[k];
             if (p >= ws && p < i) res = p;
         }
         if (res < 0) res = S.SA[kdn];
         MP(9)
-        return res;
-    }
-    int best = kdn;
-    const int c2 = (i - 1) >> LZSS_SHORT_ADDR_BITS;  // chunk of the window's last position: entries with pos < i
-    const int lo1 = lo < 1 ? 1 : lo;                 // rank 0 is the sentinel, in no chunk
-    const uint16_t *dir = S.cdir + (size_t)((lo1 - 1) >> 6) * S.nch;
-    {
-        const int beg = c2 << LZSS_SHORT_ADDR_BITS;
-        const int end = (beg + LZSS_SHORT_WINDOW) < S.n ? (beg + LZSS_SHORT_WINDOW) : S.n;
-        const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2], end, lo1);
+    } else if (is_short) {
+        int best = kdn;
+        const int c2 = (i - 1) >> LZSS_SHORT_ADDR_BITS;  // chunk of the window's last position: entries with pos < i
+        const int lo1 = lo < 1 ? 1 : lo;                 // rank 0 is the sentinel, in no chunk
+        const uint16_t *dir = S.cdir + (size_t)((lo1 - 1) >> 6) * S.nch;
+        {
+            const int beg = c2 << LZSS_SHORT_ADDR_BITS;
+            const int end = (beg + LZSS_SHORT_WINDOW) < S.n ? (beg + LZSS_SHORT_WINDOW) : S.n;
+            const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2], end, lo1);
+            const int j = next_thr<true>(S.PS, S.pmin1, S.pmin2, a, end, i);
+            if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
+        }
+        if (c2 >= 1 && ws < (c2 << LZSS_SHORT_ADDR_BITS)) {  // previous chunk: entries with pos >= ws
+            const int beg = (c2 - 1) << LZSS_SHORT_ADDR_BITS;
+            const int end = beg + LZSS_SHORT_WINDOW;
+            const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2 - 1], end, lo1);
+            const int j = next_thr<false>(S.PS, S.pmax1, S.pmax2, a, end, ws);
+            if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
+        }
+        res = S.SA[best];
         MP(10)
-        const int j = next_thr<true>(S.PS, S.pmin1, S.pmin2, a, end, i);
-        if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
-        MP(11)
-    }
-    if (c2 >= 1 && ws < (c2 << LZSS_SHORT_ADDR_BITS)) {  // previous chunk: entries with pos >= ws
-        const int beg = (c2 - 1) << LZSS_SHORT_ADDR_BITS;
-        const int end = beg + LZSS_SHORT_WINDOW;
-        const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2 - 1], end, lo1);
-        MP(10)
-        const int j = next_thr<false>(S.PS, S.pmax1, S.pmax2, a, end, ws);
-        if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
-        MP(11)
-    }
-    const int res = S.SA[best];
-    MP(11)
-    return res;
-}
-
-// the same for the LONG window [ws, i); ws == 0 whenever i <= 2^21, and then "pos < i" over the suffix
-// array itself is a one-sided condition
-__device__ inline int leftmost_long(const SegIndex &S, int kdn, int L, int ws, int i MP_ARG) {
-    const int lo = prev_lower(S.LCP, S.b1, S.b2, kdn, L);
-    MP(12)
-    int res = -1;
-    if (ws == 0 && kdn - lo > LINEAR_SPAN) {
+    } else {
         const int k = next_thr<true>(S.SA, S.samin1, S.samin2, lo, kdn + 1, i);
         res = S.SA[k <= kdn ? k : kdn];
-    } else {
-        for (int k = lo; k < kdn && res < 0; ++k) {
-            const int p = S.SA[k];
-            if (p >= ws && p < i) res = p;
-        }
-        if (res < 0) res = S.SA[kdn];
+        MP(11)
     }
-    MP(13)
     return res;
 }
 
@@ -608,31 +591,48 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     S.samin1 = ix.samin1 + sg.off / 64; S.samin2 = ix.samin2 + sg.off / 64;
     S.cdir = ix.cdir + (sg.off / 64) * ix.nch; S.nch = (int)ix.nch;
     S.n = n;
-    // short window
-    int Ls = 0, ps = -1;
+    // lengths in both windows (compress.go:146-159)
+    int Ls = 0, LL = 0;
+    bool upS = false, upL = false;  // the upper neighbour alone attains the length: it IS the smallest-rank occurrence
     if (work) {
         const int ld = LdnS >= minS ? LdnS : 0, lu = LupS >= minS ? LupS : 0;
         Ls = ld > lu ? ld : lu;
-        if (Ls > 0) ps = (lu > ld) ? pupS : ((ablate & 2) ? SA[kdnS] : leftmost_short(S, kdnS, Ls, wsS, i MP_PASS));
+        upS = lu > ld;
     }
-    MP(5)
-    // long window
-    int LL = 0, pL = -1;
     if (work && dynOK) {
         const int ld = LdnL >= minD ? LdnL : 0, lu = LupL >= minD ? LupL : 0;
         LL = ld > lu ? ld : lu;
-        if (LL > 0) pL = (lu > ld) ? pupL : ((ablate & 2) ? SA[kdnL] : leftmost_long(S, kdnL, LL, wsL, i MP_PASS));
+        upL = lu > ld;
     }
-    MP(6)
+    MP(5)
     // dictionary (compress.go:460-466): every lane searches on its own.  (Sharing the search between the lanes of a
     // wave - their lower bounds are monotone in rank - was measured slower: the phases serialise the probe latency
     // and a divergent probe loop costs the same issue slots however few lanes run it.)
     int Ld = 0, pd = -1;
     if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, ablate);
     MP(7)
+    // selection (compress.go:160-169) BEFORE the offsets: only the window whose reference is emitted needs its
+    // smallest-rank occurrence, so every lane runs at most one interval search
+    const bool from_dict = dynOK && Ld >= minD && Ld > LL;  // compress.go:464: strictly longer
+    const int Ldyn = dynOK ? (from_dict ? Ld : LL) : 0;
+    const bool short_wins = work && Ls > 0 && Ls >= Ldyn;   // 8*Ls-30 > 8*Ldyn-37 (compress.go:165)
+    const bool long_wins = work && !short_wins && Ldyn > 0 && !from_dict;
+    int p = -1;
+    if (short_wins || long_wins) {
+        const bool up = short_wins ? upS : upL;
+        const int kdn = short_wins ? kdnS : kdnL;
+        if (up) p = short_wins ? pupS : pupL;
+        else if (ablate & 2) p = SA[kdn];
+        else p = leftmost(S, kdn, short_wins ? Ls : LL, short_wins ? wsS : wsL, i, short_wins MP_PASS);
+    }
+    MP(6)
     MP_PRINT
     if (!work) return;
-    res[sg.off + i] = select_backref(D, i, minD, dynOK, Ls, ps, LL, pL, Ld, pd);
+    uint32_t out = res_pack(RES_NONE, 0, 0);
+    if (short_wins) out = res_pack(RES_SHORT, (uint32_t)Ls, (uint32_t)(i - p - 1));
+    else if (long_wins) out = res_pack(RES_DYN, (uint32_t)LL, (uint32_t)(i - p - 1));
+    else if (Ldyn > 0) out = res_pack(RES_DYN, (uint32_t)Ld, (uint32_t)(i + (int)D.n - pd - 1));  // backref.go:66, masked to 21 bits
+    res[sg.off + i] = out;
 }
 
 // positions i < HEAD: brute force over the window [0, i) (identical for both window sizes there)
