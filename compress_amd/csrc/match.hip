@@ -104,15 +104,54 @@ void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchI
 }
 
 // ---- dictionary lookup (compress.go:463: LookupLongest over [0, dictLen)) -----------------------
-// Auxiliary arrays of the dictionary index: an 8-byte big-endian prefix key per rank (one load decides
-// almost every probe of the binary search) and the rank range of every two-byte prefix (skips the first
-// probes altogether).
+// Run-aware 8-byte key of the string s[0:A), A >= 1 (readable 8 bytes past A, zeros there): first byte c (8 bits),
+// run code (9 bits), the 5 bytes after the run of c (40 bits, zero padded).  Run code: rl = length of the run of c
+// the string starts with; strings whose run ends in a smaller byte (or ends the string) come first, shorter runs
+// first: code rl (1..253); then runs of >= DICT_RUN_CAP: code 255, no tail; then strings whose run ends in a larger
+// byte, longer runs first: code 511 - rl.  The key order is the string order (a proper prefix is smaller), and two
+// different keys also give the exact common prefix length (key_lcp) - so on zero-heavy data, where a plain 8-byte
+// prefix ties on every probe and every tie costs a text compare, almost every probe is decided by one load.
+constexpr int DICT_RUN_CAP = 254;
+__device__ inline uint64_t run_key(const uint8_t *s, int A, int &rlc) {
+    const uint32_t c = s[0];
+    const int lim = (A - 1) < DICT_RUN_CAP ? (A - 1) : DICT_RUN_CAP;
+    const int rl = 1 + lcp_bytes(s, s + 1, 0, lim);
+    if (rl >= DICT_RUN_CAP) {
+        rlc = DICT_RUN_CAP;
+        return ((uint64_t)c << 49) | (255ull << 40);
+    }
+    rlc = rl;
+    uint64_t tail = 0;
+    bool falling = true;
+    if (rl < A) {
+        const int avail = A - rl;
+        tail = __builtin_bswap64(ld8(s + rl)) >> 24;
+        if (avail < 5) tail &= ~((1ull << (8 * (5 - avail))) - 1ull);
+        falling = s[rl] < c;
+    }
+    const uint64_t code = falling ? (uint64_t)rl : (uint64_t)(511 - rl);
+    return ((uint64_t)c << 49) | (code << 40) | tail;
+}
+// common prefix length of two strings from their (different) keys; the caller caps it by the strings' lengths
+__device__ inline int key_lcp(uint64_t a, uint64_t b) {
+    if ((a ^ b) >> 49) return 0;
+    const int ca = (int)(a >> 40) & 511, cb = (int)(b >> 40) & 511;
+    const int ra = ca == 255 ? DICT_RUN_CAP : (ca < 255 ? ca : 511 - ca);
+    const int rb = cb == 255 ? DICT_RUN_CAP : (cb < 255 ? cb : 511 - cb);
+    if (ca != cb) return ra < rb ? ra : rb;
+    const uint64_t x = (a ^ b) & ((1ull << 40) - 1ull);
+    return ra + (((int)__builtin_clzll(x) - 24) >> 3);
+}
+
+// Auxiliary arrays of the dictionary index: a run-aware 8-byte key per rank (one load decides almost every probe
+// of the binary search) and the rank range of every two-byte prefix (skips the first probes altogether).
 __global__ __launch_bounds__(256) void dict_aux_kernel(const uint8_t *T, uint32_t n, const int32_t *SA, uint64_t *key,
                                                        int32_t *bstart, int32_t *bend) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;  // rank, 0 = sentinel
     if (k > n) return;
     const uint32_t q = (uint32_t)SA[k];
-    key[k] = __builtin_bswap64(ld8(T + q));  // the text is zero padded past n
+    int rlc;
+    key[k] = k == 0 ? 0ull : run_key(T + q, (int)(n - q), rlc);  // the text is zero padded past n
     if (k == 0 || q + 2 > n) return;
     const uint32_t b = ((uint32_t)T[q] << 8) | T[q + 1];
     const uint32_t qp = (uint32_t)SA[k - 1];
@@ -132,37 +171,40 @@ void launch_dict_aux(const uint8_t *d_text, uint32_t n, const int32_t *d_sa, uin
                        d_bend);
 }
 
-// exact common prefix of pat[0:maxLen) and the dictionary suffix of rank k (0 for the sentinel / virtual ranks)
-__device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen, int k, int from) {
+// exact common prefix of pat[0:maxLen) and the dictionary suffix of rank k (0 for the sentinel / virtual ranks):
+// from the keys when they differ, else by comparing text past the run the equal keys vouch for
+__device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int k) {
     if (k < 1 || k > (int)D.n) return 0;
     const int q = D.SA[k];
     const int avail = (int)D.n - q;
-    return lcp_bytes(pat, D.T + q, from, maxLen < avail ? maxLen : avail);
+    const int lim = maxLen < avail ? maxLen : avail;
+    const uint64_t kq = D.key[k];
+    if (kq != pk) {
+        const int l = key_lcp(pk, kq);
+        return l < lim ? l : lim;
+    }
+    return lcp_bytes(pat, D.T + q, prl < lim ? prl : lim, lim);
 }
 
 // Binary search of pat[0:maxLen) among the dictionary suffixes.  Invariant: suffix(lo) < pat <= suffix(hi); rank 0 is
 // the sentinel, rank n+1 is virtual.  Narrows [lo, hi] until hi == lo + 1; hi is then the lower bound of pat.
-// llo / lhi: lower bounds of lcp(pat, suffix(lo)) / lcp(pat, suffix(hi)), exact when set by a text compare.
-__device__ inline void dict_search(const DictView &D, const uint8_t *pat, int maxLen, int &lo, int &hi, int &llo, int &lhi,
-                                   int g_ablate) {
-    uint64_t pk = __builtin_bswap64(ld8(pat));
-    if (maxLen < 8) pk &= ~0ull << (8 * (8 - maxLen));
+// pk / prl: run_key of the pattern and the run length it vouches for.
+__device__ inline void dict_search(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int &lo, int &hi) {
+    int llo = 0, lhi = 0;  // lower bounds of lcp(pat, suffix(lo)) / lcp(pat, suffix(hi)) from text compares
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         const uint64_t kq = D.key[mid];
         bool suffix_less;
         int o = 0;
         if (kq != pk) {
-            suffix_less = kq < pk;  // padding zeros never make a key larger, so the key order is the suffix order
-        } else if (g_ablate & 16) {
-            suffix_less = false;
+            suffix_less = kq < pk;  // the key order is the string order
         } else {
             const int q = D.SA[mid];
             const int avail = (int)D.n - q;
             const int lim = maxLen < avail ? maxLen : avail;
             o = llo < lhi ? llo : lhi;
-            const int o8 = lim < 8 ? lim : 8;
-            o = lcp_bytes(pat, D.T + q, o > o8 ? o : o8, lim);
+            const int o1 = prl < lim ? prl : lim;
+            o = lcp_bytes(pat, D.T + q, o > o1 ? o : o1, lim);
             if (o == maxLen) suffix_less = false;          // pat is a prefix of the suffix
             else if (o == avail) suffix_less = true;       // the suffix is a proper prefix of pat
             else suffix_less = D.T[q + o] < pat[o];
@@ -189,10 +231,11 @@ __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int ma
     Ld = 0;
     pd = -1;
     if (maxLen >= 2 && !dict_bucket(D, pat, lo, hi) && minLen >= 2) return;  // nothing shares two bytes with pat
-    int llo = 0, lhi = 0;
-    dict_search(D, pat, maxLen, lo, hi, llo, lhi, g_ablate);
-    llo = dict_lcp(D, pat, maxLen, lo, llo);
-    lhi = dict_lcp(D, pat, maxLen, hi, lhi);
+    int prl;
+    const uint64_t pk = run_key(pat, maxLen, prl);
+    dict_search(D, pat, maxLen, pk, prl, lo, hi);
+    const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo);
+    const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi);
     Ld = llo > lhi ? llo : lhi;
     if (Ld <= 0) return;
     if (lhi > llo) {
