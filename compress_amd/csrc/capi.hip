@@ -99,7 +99,7 @@ struct mi355_lzss_batch {
     uint32_t max_blobs = 0;
     uint64_t cap_elems = 0;  // element capacity of the per-position arrays
     // per-position arrays
-    DevBuf text, sortA, sortB, rkA, rkB, flags, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
+    DevBuf text, sortA, sortB, rkA, rkB, flags, rlen, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
     DevBuf pmin1, pmax1, pmin2, pmax2, samin1, samin2;  // per 64 entries
     DevBuf cdir;                                        // per 64 ranks and chunk
     DevBuf entry, tilebit, headb, tailb;  // per 256-tile
@@ -135,7 +135,7 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
     if (elems > b->cap_elems) {
         const uint64_t e = elems;
 #define R(buf, bytes_per) if ((rc = b->buf.ensure((size_t)(e * (bytes_per)))) != 0) return rc;
-        R(text, 1) R(sortA, 8) R(sortB, 8) R(rkA, 4) R(rkB, 4) R(flags, 1)
+        R(text, 1) R(sortA, 8) R(sortB, 8) R(rkA, 4) R(rkB, 4) R(flags, 1) R(rlen, 1)
         R(sa, 4) R(isa, 4) R(lcp, 2) R(res, 4) R(adv, 1) R(kind, 1) R(exitoff, 1)
 #undef R
         const uint64_t e64 = e / 64 + 1, e256 = e / 256 + 1;
@@ -168,6 +168,7 @@ static SaWork sa_work(mi355_lzss_batch *b) {
     w.keyB = b->sortB.as<int32_t>(); w.valB = w.keyB + b->cap_elems;
     w.rkA = b->rkA.as<int32_t>(); w.rkB = b->rkB.as<int32_t>();
     w.flags = b->flags.as<uint8_t>();
+    w.rlen = b->rlen.as<uint8_t>();
     w.sa = b->sa.as<int32_t>(); w.isa = b->isa.as<int32_t>();
     return w;
 }
@@ -175,6 +176,7 @@ static BatchIndex batch_index(mi355_lzss_batch *b) {
     BatchIndex ix;
     ix.text = b->text.as<uint8_t>();
     ix.sa = b->sa.as<int32_t>(); ix.isa = b->isa.as<int32_t>();
+    ix.rlen = b->rlen.as<uint8_t>();
     ix.lcp = b->lcp.as<uint16_t>(); ix.bmin1 = b->b1.as<uint16_t>(); ix.bmin2 = b->b2.as<uint16_t>();
     ix.ks = b->sortA.as<int32_t>(); ix.ps = ix.ks + b->cap_elems;  // the sort buffers are free once sa_build is done
     ix.pmin1 = b->pmin1.as<int32_t>(); ix.pmax1 = b->pmax1.as<int32_t>();
@@ -222,7 +224,7 @@ extern "C" int mi355_lzss_batch_create(mi355_lzss_ctx *ctx, uint32_t max_blobs, 
 extern "C" void mi355_lzss_batch_destroy(mi355_lzss_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    DevBuf *bufs[] = {&b->text, &b->sortA, &b->sortB, &b->rkA, &b->rkB, &b->flags, &b->sa, &b->isa,
+    DevBuf *bufs[] = {&b->text, &b->sortA, &b->sortB, &b->rkA, &b->rkB, &b->flags, &b->rlen, &b->sa, &b->isa,
                       &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->cdir, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
                       &b->headb, &b->tailb, &b->segs, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->out,
                       &b->d_cin, &b->d_cin_off, &b->d_dout, &b->d_dout_off, &b->d_dlen, &b->d_dstatus};

@@ -11,6 +11,7 @@ struct SaWork {       // batch-wide arrays, indexed [seg.off + k], k in [0, n]
     int32_t *rkA, *rkB;                  // group ranks, double buffered
     uint8_t *flags;                      // group-boundary flags
     int32_t *sa, *isa;                   // outputs
+    uint8_t *rlen;                       // output: length of the run of equal bytes starting at every position, capped at 255
 };
 void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
                      hipStream_t stream);
@@ -32,6 +33,7 @@ struct BatchIndex {   // batch-wide index arrays
     const uint8_t *text;
     int32_t *sa, *isa;
     uint16_t *lcp;    // [seg.off + k]
+    const uint8_t *rlen;  // [seg.off + i] run of equal bytes starting at position i, capped at 255 (sa_build)
     uint16_t *bmin1;  // [seg.off/64 + k/64]
     uint16_t *bmin2;  // [seg.off/64 + k/4096]
     // window index (sa_build.hip: window_index_kernel): the ranks 1..n regrouped by the 16 KiB chunk of

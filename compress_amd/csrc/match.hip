@@ -54,27 +54,43 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, Batch
     if (blockIdx.x * LCP_THREADS >= N) return;
     const uint32_t k = blockIdx.x * LCP_THREADS + threadIdx.x;
     const uint8_t *T = ix.text + sg.off;
+    const uint8_t *RL = ix.rlen + sg.off;
     const int32_t *SA = ix.sa + sg.off;
     uint32_t l = 0xFFFFu;
+    int sak = INT_MAX;
     if (k < N) {
         l = 0;
+        sak = SA[k];
         if (k > 0) {
-            const uint32_t a = (uint32_t)SA[k - 1], b = (uint32_t)SA[k];
+            const uint32_t a = (uint32_t)SA[k - 1], b = (uint32_t)sak;
             const uint32_t hi = a > b ? a : b;
             int lim = (int)(sg.n - hi);  // the shorter suffix ends at the sentinel
             if (lim > LZSS_MAX_LEN) lim = LZSS_MAX_LEN;
-            l = (uint32_t)lcp_bytes(T + a, T + b, 0, lim);
+            // both suffixes start with a run of equal bytes: different run lengths settle the answer without a
+            // text compare, equal ones let it start behind the run (long runs are what makes LCPs long here)
+            if (lim > 0 && T[a] == T[b]) {
+                const int ra = RL[a], rb = RL[b];  // capped at 255
+                const int r = ra < rb ? ra : rb;
+                if (ra != rb) l = (uint32_t)(r < lim ? r : lim);
+                else l = (uint32_t)lcp_bytes(T + a, T + b, r < lim ? r : lim, lim);
+            }
         }
         ix.lcp[sg.off + k] = (uint16_t)l;
     }
-    // minimum over the 64 ranks of this wave
+    // minimum of LCP and of SA over the 64 ranks of this wave
     uint32_t m = l;
+    int ms = sak;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+        const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+        const int u = __shfl_xor(ms, o);
         m = t < m ? t : m;
+        ms = u < ms ? u : ms;
     }
-    if ((threadIdx.x & 63) == 0) ix.bmin1[sg.off / 64 + (k >> 6)] = (uint16_t)m;
+    if ((threadIdx.x & 63) == 0) {
+        ix.bmin1[sg.off / 64 + (k >> 6)] = (uint16_t)m;
+        ix.samin1[sg.off / 64 + (k >> 6)] = ms;
+    }
 }
 
 __global__ __launch_bounds__(64) void bmin2_kernel(const Seg *segs, BatchIndex ix) {

@@ -46,6 +46,17 @@ __device__ inline uint64_t match_digit(int d, uint64_t amask) {
     return peers;
 }
 
+// the same with a runtime number of digit bits (wave-uniform)
+__device__ inline uint64_t match_digit_n(int d, uint64_t amask, int nbits) {
+    uint64_t peers = amask;
+    for (int bit = 0; bit < nbits; ++bit) {
+        const bool b = (d >> bit) & 1;
+        const uint64_t bal = __ballot(b);
+        peers &= b ? bal : ~bal;
+    }
+    return peers;
+}
+
 __device__ inline int wave_incl_add(int v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -368,6 +379,37 @@ constexpr int SA_WSPAN = 64 * SA_K;            // consecutive entries of one wav
 constexpr int SA_TILE = SAM_THREADS * SA_K;
 
 constexpr int SA_RUN_CAP = 254;  // runs of equal symbols are told apart by length up to here
+
+// Length of the run of equal bytes that starts at position e of the text (1 at and past its end), exact up to 257:
+// the lanes of a wave hold 64 consecutive positions and read the run off five ballots of "byte == next byte".
+__device__ inline int run_length_64(const uint8_t *T, uint32_t n, uint32_t e, int lane) {
+    uint64_t E[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const uint32_t q = e + 64 * t;
+        E[t] = __ballot(q + 1 < n && T[q] == T[q + 1]);
+    }
+    const uint64_t x0 = E[0] >> lane;  // the top `lane` bits are zero
+    int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);  // ones from this lane's bit on, <= 64 - lane
+    if (rl == 64 - lane) {
+#pragma unroll
+        for (int t = 1; t < 5; ++t) {
+            const int rt = E[t] == ~0ull ? 64 : (int)__builtin_ctzll(~E[t]);
+            rl += rt;
+            if (rt < 64) break;
+        }
+    }
+    return rl + 1;
+}
+
+// run lengths for the texts the fallback kernel sorts (the main kernel writes them in its first sweep)
+__global__ __launch_bounds__(256) void rlen_kernel(const Seg *segs, const uint8_t *text, uint8_t *rlen) {
+    const Seg sg = segs[blockIdx.y];
+    if (blockIdx.x * 256 > sg.n) return;
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    const int rl = run_length_64(text + sg.off, sg.n, e, threadIdx.x & 63);
+    if (e <= sg.n) rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
+}
 
 // the first SA_INIT_SYMS symbols of suffix p (0 = sentinel, byte + 1 otherwise), 9 bits each
 __device__ inline uint64_t init_key(const uint8_t *T, uint32_t n, uint32_t p) {
@@ -777,24 +819,8 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     int32_t *hY = (int32_t *)L.act, *hX = hY + NB, *hC = L.hl, *hS = L.hh;  // act is free until the first regroup
     for (uint32_t e0 = (uint32_t)w * 64; e0 < N; e0 += SAM_THREADS) {
         const uint32_t e = e0 + lane;
-        // eq bit of position q: symbol(q) == symbol(q + 1); five words cover the run cap
-        uint64_t E[5];
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const uint32_t q = e + 64 * t;
-            E[t] = __ballot(q + 1 < n && T[q] == T[q + 1]);
-        }
-        const uint64_t x0 = E[0] >> lane;  // the top `lane` bits are zero
-        int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);  // ones from this lane's bit on, <= 64 - lane
-        if (rl == 64 - lane) {
-#pragma unroll
-            for (int t = 1; t < 5; ++t) {
-                const int rt = E[t] == ~0ull ? 64 : (int)__builtin_ctzll(~E[t]);
-                rl += rt;
-                if (rt < 64) break;
-            }
-        }
-        rl += 1;
+        const int rl = run_length_64(T, n, e, lane);
+        if (e < N) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
         uint64_t rec = 0;
         int dY = 0, dX = 0, dC = 0, dS = 0;
         const bool valid = e < N;
@@ -1018,13 +1044,15 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
     const uint32_t C = (((n + SA_WAVES - 1) / SA_WAVES) + 63u) & ~63u;
     const uint32_t cbeg = 1 + min((uint32_t)w * C, n), cend = min(cbeg + C, N);
 
+    const int cbits = nch > 1 ? 32 - __clz(nch - 1) : 0;  // bits of a chunk number
     hist_clear(sh, tid);
     __syncthreads();
     for (uint32_t k0 = cbeg; k0 < cend; k0 += 64) {
         const uint32_t k = k0 + lane;
         const bool active = k < cend;
         const int c = active ? (SA[k] >> WIN_SHIFT) : 0;
-        hist_add(sh.hist[w], c, active, lane);
+        const uint64_t peers = match_digit_n(c, __ballot(active), cbits);
+        if (active && (peers & lanemask_lt(lane)) == 0) sh.hist[w][c] += __popcll(peers);
     }
     __syncthreads();
     if (tid < nch) {  // first slot of wave w inside chunk tid
@@ -1047,7 +1075,7 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
         for (int cc = lane; cc < nch; cc += 64) cdir[((k0 - 1) >> 6) * ix.nch + cc] = (uint16_t)(hrow[cc] - (cc << WIN_SHIFT));
         __builtin_amdgcn_wave_barrier();
         const uint64_t amask = __ballot(active);
-        const uint64_t peers = match_digit(c, amask);
+        const uint64_t peers = match_digit_n(c, amask, cbits);
         const int cnt = __popcll(peers);
         const int rank = __popcll(peers & lanemask_lt(lane));
         const int base = hrow[c];
@@ -1084,17 +1112,44 @@ __global__ __launch_bounds__(256) void block64_kernel(const Seg *segs, const int
     if ((threadIdx.x & 63) == 0) out[sg.off / 64 + (j >> 6)] = v;
 }
 
+// min of imin and max of imax over blocks of 64 entries.  level 0: imin == imax == the array itself (n entries per
+// segment at [off + j]); level 1: the level-0 minima / maxima ([off/64 + j], ceil(n / 64) entries)
+__global__ __launch_bounds__(256) void block64_minmax_kernel(const Seg *segs, const int32_t *imin, const int32_t *imax,
+                                                             int32_t *omin, int32_t *omax, int level) {
+    const Seg sg = segs[blockIdx.y];
+    uint32_t count = sg.n;
+    uint64_t base = sg.off;
+    if (level == 1) {
+        count = (count + 63) / 64;
+        base = sg.off / 64;
+    }
+    if (blockIdx.x * 256 >= count) return;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    int lo = INT_MAX, hi = INT_MIN;
+    if (j < count) {
+        lo = imin[base + j];
+        hi = imax[base + j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        omin[sg.off / 64 + (j >> 6)] = lo;
+        omax[sg.off / 64 + (j >> 6)] = hi;
+    }
+}
+
 void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream) {
     if (n_segs == 0 || max_n == 0) return;
     hipLaunchKernelGGL(window_index_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, ix);
     const uint32_t c0 = max_n + 1, c1 = (c0 + 63) / 64;
     dim3 g0((c0 + 255) / 256, n_segs), g1((c1 + 255) / 256, n_segs);
-    hipLaunchKernelGGL(block64_kernel<false>, g0, dim3(256), 0, stream, d_segs, ix.ps, ix.pmin1, 0, 0);
-    hipLaunchKernelGGL(block64_kernel<true>, g0, dim3(256), 0, stream, d_segs, ix.ps, ix.pmax1, 0, 0);
-    hipLaunchKernelGGL(block64_kernel<false>, g0, dim3(256), 0, stream, d_segs, ix.sa, ix.samin1, 0, 1);
-    hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.pmin1, ix.pmin2, 1, 0);
-    hipLaunchKernelGGL(block64_kernel<true>, g1, dim3(256), 0, stream, d_segs, ix.pmax1, ix.pmax2, 1, 0);
-    hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.samin1, ix.samin2, 1, 1);
+    hipLaunchKernelGGL(block64_minmax_kernel, g0, dim3(256), 0, stream, d_segs, ix.ps, ix.ps, ix.pmin1, ix.pmax1, 0);
+    hipLaunchKernelGGL(block64_minmax_kernel, g1, dim3(256), 0, stream, d_segs, ix.pmin1, ix.pmax1, ix.pmin2, ix.pmax2, 1);
+    hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.samin1, ix.samin2, 1, 1);  // samin1: lcp_kernel
 }
 
 void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
@@ -1118,6 +1173,7 @@ void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const u
                            d_segs, d_text, wk, max_rounds);
     } else {
         hipLaunchKernelGGL(sa_build_full_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, d_text, wk);
+        hipLaunchKernelGGL(rlen_kernel, dim3((N + 255) / 256, n_segs), dim3(256), 0, stream, d_segs, d_text, wk.rlen);
     }
 }
 
