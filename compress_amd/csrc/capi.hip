@@ -317,7 +317,7 @@ static int run_walk_emit(mi355_lzss_batch *b, uint32_t header_bytes, uint32_t bi
     int rc;
     const Seg *d_segs = b->segs.as<Seg>();
     WalkWork ww = walk_work(b);
-    launch_decide(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), b->res.as<uint32_t>(), ww, sm);
+    launch_decide(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), b->rlen.as<uint8_t>(), b->res.as<uint32_t>(), ww, sm);
     if ((rc = mark(b, ST_WALK)) != 0) return rc;
     launch_walk(d_segs, b->n_blobs, ww, header_bytes, bit_off, sm);
     launch_out_offsets(b->n_blobs, ww, sm);

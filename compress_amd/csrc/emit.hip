@@ -27,8 +27,8 @@ __device__ inline int savings_of(uint32_t r) {  // backref.savings, lzss/backref
     return 8 * (int)res_len(r) - (t == RES_SHORT ? LZSS_SHORT_BITS : LZSS_DYN_BITS);
 }
 
-__global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs, const uint8_t *text, const uint32_t *res,
-                                                                uint8_t *adv_out, uint8_t *kind_out) {
+__global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs, const uint8_t *text, const uint8_t *rlen,
+                                                                const uint32_t *res, uint8_t *adv_out, uint8_t *kind_out) {
     const Seg sg = segs[blockIdx.y];
     const int n = (int)sg.n;
     const int i = (int)(blockIdx.x * DECIDE_THREADS + threadIdx.x);
@@ -40,19 +40,9 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs,
 
     // run of equal bytes starting at i, capped at 256 and at the end of the buffer (compress.go:180-183)
     const int lim = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
-    int count = 0;
-    {
-        const uint64_t pat = 0x0101010101010101ull * c;
-        while (count < lim) {
-            const uint64_t x = ld8(T + i + count) ^ pat;
-            if (x) {
-                count += (int)(__builtin_ctzll(x) >> 3);
-                break;
-            }
-            count += 8;
-        }
-        if (count > lim) count = lim;
-    }
+    int count = rlen[sg.off + i];  // the suffix sort's run lengths, capped at 255
+    if (count == 255 && lim > 255 && T[i + 255] == c) count = 256;
+    if (count > lim) count = lim;
     int advance;
     uint8_t kind;
     if (count >= LZSS_MIN_REPEAT) {  // compress.go:184-218
@@ -85,11 +75,11 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs,
     kind_out[sg.off + i] = kind;
 }
 
-void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint32_t *d_res,
-                   const WalkWork &ww, hipStream_t stream) {
+void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint8_t *d_rlen,
+                   const uint32_t *d_res, const WalkWork &ww, hipStream_t stream) {
     if (n_segs == 0 || max_n == 0) return;
     dim3 g((max_n + DECIDE_THREADS - 1) / DECIDE_THREADS, n_segs);
-    hipLaunchKernelGGL(decide_kernel, g, dim3(DECIDE_THREADS), 0, stream, d_segs, d_text, d_res, ww.adv, ww.kind);
+    hipLaunchKernelGGL(decide_kernel, g, dim3(DECIDE_THREADS), 0, stream, d_segs, d_text, d_rlen, d_res, ww.adv, ww.kind);
 }
 
 // ---- walk: visited tiles, per-tile bit offsets, per-blob size -------------------------------------

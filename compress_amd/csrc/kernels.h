@@ -70,8 +70,9 @@ struct WalkWork {
     uint64_t *out_off;  // [seg], n_segs+1 entries: byte offset of the blob's output in the batch output buffer
     uint32_t *out_len;  // [seg] bytes written (header + ceil(bits/8))
 };
-void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint32_t *d_res,
-                   const WalkWork &ww, hipStream_t stream);
+// d_rlen: run lengths of the suffix sort (SaWork::rlen)
+void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint8_t *d_rlen,
+                   const uint32_t *d_res, const WalkWork &ww, hipStream_t stream);
 // header_bytes: 3 (one-shot Compress) or 0; bit_off: first bit of the stream inside its first byte (streaming Write)
 void launch_walk(const Seg *d_segs, uint32_t n_segs, const WalkWork &ww, uint32_t header_bytes, uint32_t bit_off,
                  hipStream_t stream);

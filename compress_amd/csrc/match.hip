@@ -413,14 +413,8 @@ __device__ inline int leftmost(const SegIndex &S, int kdn, int L, int ws, int i,
 
 // true when the walk can never call bestBackref(i): i, i-1 and i-2 lie in one run of equal bytes and at
 // least 160 of them follow i, so the RLE branch (compress.go:184) is taken at i, i-1 and i-2
-__device__ inline bool never_queried(const uint8_t *T, int n, int i) {
-    if (i < 2 || n - i < LZSS_MIN_REPEAT) return false;
-    const uint8_t c = T[i];
-    if (T[i - 1] != c || T[i - 2] != c) return false;
-    const uint64_t pat = 0x0101010101010101ull * c;
-    for (int o = 0; o < LZSS_MIN_REPEAT; o += 8)
-        if (ld8(T + i + o) != pat) return false;
-    return true;
+__device__ inline bool never_queried(const uint8_t *RL, int i) {
+    return i >= 2 && RL[i - 2] >= LZSS_MIN_REPEAT + 2;  // run lengths of the suffix sort, capped at 255
 }
 
 #ifndef MATCH_SCAN_CAP
@@ -464,7 +458,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
         i = SA[r];
         work = !(i < (int)sg.start || i < HEAD);
     }
-    if (work && skip_unqueried && never_queried(T, n, i)) {
+    if (work && skip_unqueried && never_queried(ix.rlen + sg.off, i)) {
         res[sg.off + i] = res_pack(RES_NONE, 0, 0);
         work = false;
     }
