@@ -118,6 +118,17 @@ __device__ inline int lcp_bytes(const uint8_t *a, const uint8_t *b, int from, in
     return o < lim ? o : lim;
 }
 
+// common prefix length of the suffixes at a and b (a != b), at most lim, with the run lengths RL of the text (length
+// of the run of equal bytes starting at every position, capped at 255): different run lengths settle the answer
+// without a text compare, equal ones let it start behind the run (long runs are what makes prefixes long here)
+__device__ inline int lcp_run(const uint8_t *T, const uint8_t *RL, uint32_t a, uint32_t b, int lim) {
+    if (lim <= 0 || T[a] != T[b]) return 0;
+    const int ra = RL[a], rb = RL[b];
+    const int r = ra < rb ? ra : rb;
+    if (ra != rb) return r < lim ? r : lim;
+    return lcp_bytes(T + a, T + b, r < lim ? r : lim, lim);
+}
+
 typedef uint16_t u16x8_t __attribute__((ext_vector_type(8)));
 
 // largest index <= j inside the 8-aligned group of j whose value is < L, or -1 (one 16-byte load)

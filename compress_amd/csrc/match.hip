@@ -66,14 +66,7 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, Batch
             const uint32_t hi = a > b ? a : b;
             int lim = (int)(sg.n - hi);  // the shorter suffix ends at the sentinel
             if (lim > LZSS_MAX_LEN) lim = LZSS_MAX_LEN;
-            // both suffixes start with a run of equal bytes: different run lengths settle the answer without a
-            // text compare, equal ones let it start behind the run (long runs are what makes LCPs long here)
-            if (lim > 0 && T[a] == T[b]) {
-                const int ra = RL[a], rb = RL[b];  // capped at 255
-                const int r = ra < rb ? ra : rb;
-                if (ra != rb) l = (uint32_t)(r < lim ? r : lim);
-                else l = (uint32_t)lcp_bytes(T + a, T + b, r < lim ? r : lim, lim);
-            }
+            l = (uint32_t)lcp_run(T, RL, a, b, lim);
         }
         ix.lcp[sg.off + k] = (uint16_t)l;
     }
@@ -695,6 +688,7 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
     const int i = (int)(blockIdx.x * 64 + threadIdx.x);
     if (i >= n || i >= HEAD || i < (int)sg.start) return;
     const uint8_t *T = ix.text + sg.off;
+    const uint8_t *RL = ix.rlen + sg.off;
     const int32_t *ISA = ix.isa + sg.off;
 
     const int maxLen = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
@@ -706,7 +700,7 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
     int best = 0, bp = -1, brank = 0x7FFFFFFF;
     if (shortOK) {
         for (int p = 0; p < i; ++p) {
-            const int l = lcp_bytes(T + p, T + i, 0, maxLen);
+            const int l = lcp_run(T, RL, (uint32_t)p, (uint32_t)i, maxLen);
             if (l < minS || l < best) continue;
             const int rk = ISA[p];
             if (l > best || rk < brank) { best = l; bp = p; brank = rk; }
