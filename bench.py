@@ -26,7 +26,7 @@ def pmc_traffic(stage, n_blobs):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same command, KB -> bytes).  FETCH_SIZE is left uncorrected:
     the guide's x2 applies to wide coalesced streams only and these kernels mix 2/4/8/16-byte accesses."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.csv")
+    path = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.csv")
     kernel = {"sa_build": "lzss::sa_build_kernel", "match": "lzss::match_kernel", "lcp": "lzss::lcp_kernel"}.get(stage)
     if kernel is None or not os.path.exists(path) or n_blobs != 1250:
         return None, None
@@ -36,7 +36,7 @@ def pmc_traffic(stage, n_blobs):
         if k.replace("void ", "").split("<")[0] == kernel:
             total += float(v) * 1024.0  # one batch launch (steps 1, warmup 0); a second dispatch is the dictionary's
                                         # single 64 KiB segment at context creation, < 0.1 % of the batch's traffic
-    return int(total), "profiles/r01_c_pmc_hbm_traffic.csv (rocprofv3 --pmc, FETCH_SIZE + WRITE_SIZE, per launch)"
+    return int(total), "profiles/r01_d_pmc_hbm_traffic.csv (rocprofv3 --pmc, FETCH_SIZE + WRITE_SIZE, per launch)"
 
 
 def main():
