@@ -61,6 +61,26 @@ def test_index_matches_oracle(amd):
             assert lcp[r] == l
 
 
+def test_text_sizes_across_the_suffix_sort_variants(amd, dict_naive):
+    """the suffix sort has three code paths by text size: 9-bit digits (N <= 2^18), 10-bit digits (N <= 300 000) and
+    the every-round-sorts-everything fallback above; a batch picks one by its LARGEST text, so each is exercised
+    with a ragged batch (small texts ride along) and checked on index and bytes"""
+    big = b"".join(amd.synth.blob(k) for k in range(20, 23))  # 384 KiB of calldata-like bytes
+    for n_big in (262143, 262144, 280000, 299999, 300001):
+        cases = [big[:n_big], b"", b"x", amd.synth.blob(3)[:5000], bytes(70000)]
+        ctx = amd.batch.new_ctx(dict_naive)
+        b = amd.batch.Batch(ctx, len(cases), sum(map(len, cases)))
+        b.upload(cases)
+        b.compress()
+        got = b.download()
+        oc = O.Compressor(dict_naive)
+        for k, d in enumerate(cases):
+            sa, isa, lcp = b.index(k)
+            assert sa[0] == len(d)
+            assert np.array_equal(sa[1:], O.suffix_array(d)), f"n_big={n_big} case {k}"
+            assert got[k] == oc.compress(d), f"n_big={n_big} case {k}"
+
+
 def unpack(amd_ty, amd_addr, amd_len):
     return list(zip(amd_ty.tolist(), amd_addr.tolist(), amd_len.tolist()))
 
