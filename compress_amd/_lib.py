@@ -13,6 +13,7 @@ _vp, _sz, _u32, _u64, _i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c
 SIGNATURES = {
     "mi355_lzss_ctx_create": (_i32, [_vp, _sz, _i32, C.POINTER(_vp)]),
     "mi355_lzss_ctx_destroy": (None, [_vp]),
+    "mi355_lzss_ctx_set_overlap": (_i32, [_vp, _i32]),
     "mi355_lzss_last_error": (C.c_char_p, []),
     "mi355_lzss_dict_info": (_i32, [_vp, C.POINTER(_u64), C.POINTER(C.c_int32 * 2)]),
     "mi355_lzss_best_backrefs": (_i32, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),

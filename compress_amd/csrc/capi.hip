@@ -76,7 +76,6 @@ struct PinBuf {
     T *as() const { return (T *)p; }
 };
 
-static inline uint64_t seg_stride(uint64_t n) { return (n + SEG_PAD + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN; }
 
 // ---- objects ----------------------------------------------------------------------------------------
 enum { ST_SA = 0, ST_LCP, ST_WINDEX, ST_MHEAD, ST_MATCH, ST_DECIDE, ST_WALK, ST_EMIT, ST_DECOMP, ST_COUNT };
@@ -92,6 +91,11 @@ struct mi355_lzss_ctx {
     DevBuf d_text, d_sa, d_isa, d_lcp, d_b1, d_b2, d_key, d_bstart, d_bend;
     DictView view{};
     mi355_lzss_batch *scratch = nullptr;  // for the single-buffer entry points
+    // side streams + events for running the index / match stages of sub-batches concurrently
+    static constexpr int kMaxSplit = 4;
+    hipStream_t side[kMaxSplit] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[kMaxSplit] = {};
+    int split = 1;
 };
 
 struct mi355_lzss_batch {
@@ -178,7 +182,7 @@ static BatchIndex batch_index(mi355_lzss_batch *b) {
     ix.sa = b->sa.as<int32_t>(); ix.isa = b->isa.as<int32_t>();
     ix.rlen = b->rlen.as<uint8_t>();
     ix.lcp = b->lcp.as<uint16_t>(); ix.bmin1 = b->b1.as<uint16_t>(); ix.bmin2 = b->b2.as<uint16_t>();
-    ix.ks = b->sortA.as<int32_t>(); ix.ps = ix.ks + b->cap_elems;  // the sort buffers are free once sa_build is done
+    ix.win = b->sortA.as<uint64_t>();  // a segment's part of the sort buffer is free once the segment is sorted
     ix.pmin1 = b->pmin1.as<int32_t>(); ix.pmax1 = b->pmax1.as<int32_t>();
     ix.pmin2 = b->pmin2.as<int32_t>(); ix.pmax2 = b->pmax2.as<int32_t>();
     ix.samin1 = b->samin1.as<int32_t>(); ix.samin2 = b->samin2.as<int32_t>();
@@ -282,20 +286,52 @@ extern "C" int mi355_lzss_batch_upload(mi355_lzss_batch *b, const uint8_t *in, c
 
 // index build + match search for the uploaded blobs
 static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
-    hipStream_t sm = b->ctx->stream;
+    mi355_lzss_ctx *ctx = b->ctx;
+    hipStream_t sm = ctx->stream;
     int rc;
     const Seg *d_segs = b->segs.as<Seg>();
+    int split = ctx->split;
+    if (b->n_blobs < 8u * (uint32_t)split || b->max_n + 1 > SA_BITMAP_MAX_N) split = 1;
+    if (split == 1) {
+        if ((rc = mark(b, ST_SA)) != 0) return rc;
+        launch_sa_build(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
+        if ((rc = mark(b, ST_LCP)) != 0) return rc;
+        launch_lcp(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
+        if ((rc = mark(b, ST_WINDEX)) != 0) return rc;
+        launch_window_index(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
+        if ((rc = mark(b, ST_MHEAD)) != 0) return rc;
+        launch_match_head(d_segs, b->n_blobs, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), sm);
+        if ((rc = mark(b, ST_MATCH)) != 0) return rc;
+        launch_match(d_segs, b->n_blobs, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), skip_unqueried, sm);
+        if ((rc = mark(b, ST_DECIDE)) != 0) return rc;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // sub-batches on side streams: the tail of one sub-batch's suffix sort (a third wave of workgroups that fills
+    // less than half of the CUs) overlaps the next stages of another; per-stage events lose their meaning here
+    if (!ctx->fork_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    for (int k = 1; k < split; ++k) {
+        if (!ctx->side[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+        if (!ctx->join_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->join_ev[k], hipEventDisableTiming));
+    }
     if ((rc = mark(b, ST_SA)) != 0) return rc;
-    launch_sa_build(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
-    if ((rc = mark(b, ST_LCP)) != 0) return rc;
-    launch_lcp(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
-    if ((rc = mark(b, ST_WINDEX)) != 0) return rc;
-    launch_window_index(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
-    if ((rc = mark(b, ST_MHEAD)) != 0) return rc;
-    launch_match_head(d_segs, b->n_blobs, b->max_n, batch_index(b), b->ctx->view, b->res.as<uint32_t>(), sm);
-    if ((rc = mark(b, ST_MATCH)) != 0) return rc;
-    launch_match(d_segs, b->n_blobs, b->max_n, batch_index(b), b->ctx->view, b->res.as<uint32_t>(), skip_unqueried, sm);
-    if ((rc = mark(b, ST_DECIDE)) != 0) return rc;
+    HIP_TRY(hipEventRecord(ctx->fork_ev, sm));
+    for (int k = 0; k < split; ++k) {
+        hipStream_t st = k == 0 ? sm : ctx->side[k];
+        const uint32_t lo = (uint32_t)((uint64_t)b->n_blobs * k / split), hi = (uint32_t)((uint64_t)b->n_blobs * (k + 1) / split);
+        const Seg *sg = d_segs + lo;
+        const uint32_t cnt = hi - lo;
+        if (k) HIP_TRY(hipStreamWaitEvent(st, ctx->fork_ev, 0));
+        launch_sa_build(sg, cnt, b->max_n, b->text.as<uint8_t>(), sa_work(b), st);
+        launch_lcp(sg, cnt, b->max_n, batch_index(b), st);
+        launch_window_index(sg, cnt, b->max_n, batch_index(b), st);
+        launch_match_head(sg, cnt, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), st);
+        launch_match(sg, cnt, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), skip_unqueried, st);
+        if (k) HIP_TRY(hipEventRecord(ctx->join_ev[k], st));
+    }
+    for (int k = 1; k < split; ++k) HIP_TRY(hipStreamWaitEvent(sm, ctx->join_ev[k], 0));
+    for (int k = ST_LCP; k <= ST_DECIDE; ++k)
+        if ((rc = mark(b, k)) != 0) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -476,6 +512,10 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(MI355_LZSS_E_DEVICE, "hipStreamCreate failed"));
 
+    if (const char *e = getenv("MI355_LZSS_SPLIT")) {
+        const int v = atoi(e);
+        ctx->split = v < 1 ? 1 : (v > mi355_lzss_ctx::kMaxSplit ? mi355_lzss_ctx::kMaxSplit : v);
+    }
     // dictionary index (compress.go:64) built with the same kernels as the input index
     mi355_lzss_batch *b = nullptr;
     if ((rc = mi355_lzss_batch_create(ctx, 1, aug.size(), &b)) != 0) return bail(rc);
@@ -520,12 +560,23 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     return 0;
 }
 
+extern "C" int mi355_lzss_ctx_set_overlap(mi355_lzss_ctx *ctx, int parts) {
+    if (!ctx || parts < 1 || parts > mi355_lzss_ctx::kMaxSplit) return fail(MI355_LZSS_E_ARG, "overlap parts must be 1..%d", mi355_lzss_ctx::kMaxSplit);
+    ctx->split = parts;
+    return 0;
+}
+
 extern "C" void mi355_lzss_ctx_destroy(mi355_lzss_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->scratch) mi355_lzss_batch_destroy(ctx->scratch);
     DevBuf *bufs[] = {&ctx->d_text, &ctx->d_sa, &ctx->d_isa, &ctx->d_lcp, &ctx->d_b1, &ctx->d_b2, &ctx->d_key, &ctx->d_bstart, &ctx->d_bend};
     for (DevBuf *d : bufs) d->release();
+    for (int k = 0; k < mi355_lzss_ctx::kMaxSplit; ++k) {
+        if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
+        if (ctx->join_ev[k]) (void)hipEventDestroy(ctx->join_ev[k]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

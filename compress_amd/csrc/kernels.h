@@ -13,6 +13,9 @@ struct SaWork {       // batch-wide arrays, indexed [seg.off + k], k in [0, n]
     int32_t *sa, *isa;                   // outputs
     uint8_t *rlen;                       // output: length of the run of equal bytes starting at every position, capped at 255
 };
+// texts of more than this many suffixes are sorted by the fallback kernel, which uses the sort buffers as whole-batch
+// int32 arrays: no other stage of the batch may run beside it
+constexpr uint32_t SA_BITMAP_MAX_N = 300000;
 void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
                      hipStream_t stream);
 
@@ -36,10 +39,14 @@ struct BatchIndex {   // batch-wide index arrays
     const uint8_t *rlen;  // [seg.off + i] run of equal bytes starting at position i, capped at 255 (sa_build)
     uint16_t *bmin1;  // [seg.off/64 + k/64]
     uint16_t *bmin2;  // [seg.off/64 + k/4096]
-    // window index (sa_build.hip: window_index_kernel): the ranks 1..n regrouped by the 16 KiB chunk of
-    // their position, rank order kept inside a chunk.  Entry j of chunk c sits at [seg.off + c*16384 + j].
-    int32_t *ks;      // rank of the entry
-    int32_t *ps;      // position of the entry (== sa[ks])
+    // window index (sa_build.hip: window_index_kernel): the ranks 1..n regrouped by the 16 KiB chunk of their
+    // position, rank order kept inside a chunk.  It lives in the segment's OWN part of the suffix sort's record
+    // buffer (free once the segment is sorted; other segments may still be sorting theirs on another stream):
+    // win + seg.off holds seg_stride(n) 8-byte records = 2 * seg_stride(n) int32: first the ranks, then the positions.
+    uint64_t *win;
+    __host__ __device__ int32_t *ks(const Seg &sg) const { return (int32_t *)(win + sg.off); }                   // rank of entry j
+    __host__ __device__ int32_t *ps(const Seg &sg) const { return (int32_t *)(win + sg.off) + seg_stride(sg.n); }  // its position
+    // entry j of chunk c sits at index c * 16384 + j of both
     int32_t *pmin1, *pmax1;  // min / max of ps over blocks of 64 entries   [seg.off/64 + j/64]
     int32_t *pmin2, *pmax2;  // ... over blocks of 4096 entries             [seg.off/64 + j/4096]
     int32_t *samin1, *samin2;  // min of sa over blocks of 64 / 4096 ranks  [seg.off/64 + k/64], [.. + k/4096]

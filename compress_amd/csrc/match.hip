@@ -631,7 +631,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     MP(4)
     SegIndex S;
     S.SA = SA; S.LCP = LCP; S.b1 = b1; S.b2 = b2;
-    S.KS = ix.ks + sg.off; S.PS = ix.ps + sg.off;
+    S.KS = ix.ks(sg); S.PS = ix.ps(sg);
     S.pmin1 = ix.pmin1 + sg.off / 64; S.pmax1 = ix.pmax1 + sg.off / 64;
     S.pmin2 = ix.pmin2 + sg.off / 64; S.pmax2 = ix.pmax2 + sg.off / 64;
     S.samin1 = ix.samin1 + sg.off / 64; S.samin2 = ix.samin2 + sg.off / 64;

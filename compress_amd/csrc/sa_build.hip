@@ -340,7 +340,6 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_full_kernel(const Seg *se
 //                  low digit of k1
 //   S2:            scatter of the records by the high digit of k1 -> sorted by (k1, sequence order)
 // Suffixes alone in their group never move again, so SA and the ranks are updated in place.
-constexpr uint32_t SA_BITMAP_MAX_N = 300000;
 constexpr int SA_INIT_SYMS = 4;  // depth of the initial sort (symbols compared straight from the text)
 #ifndef SA_MAIN_THREADS
 #define SA_MAIN_THREADS 512
@@ -1037,7 +1036,7 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
     const uint32_t N = n + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int32_t *SA = ix.sa + sg.off;
-    int32_t *KS = ix.ks + sg.off, *PS = ix.ps + sg.off;
+    int32_t *KS = ix.ks(sg), *PS = ix.ps(sg);
     const int nch = (int)((n + (1u << WIN_SHIFT) - 1) >> WIN_SHIFT);  // <= 256 for n <= 4 MiB
 
     // ranks 1..n (rank 0 is the sentinel), one chunk of the rank range per wave
@@ -1112,23 +1111,26 @@ __global__ __launch_bounds__(256) void block64_kernel(const Seg *segs, const int
     if ((threadIdx.x & 63) == 0) out[sg.off / 64 + (j >> 6)] = v;
 }
 
-// min of imin and max of imax over blocks of 64 entries.  level 0: imin == imax == the array itself (n entries per
-// segment at [off + j]); level 1: the level-0 minima / maxima ([off/64 + j], ceil(n / 64) entries)
-__global__ __launch_bounds__(256) void block64_minmax_kernel(const Seg *segs, const int32_t *imin, const int32_t *imax,
-                                                             int32_t *omin, int32_t *omax, int level) {
+// min and max over blocks of 64 entries.  level 0: of the positions of the window index (n entries per segment);
+// level 1: of the level-0 minima / maxima ([off/64 + j], ceil(n / 64) entries)
+__global__ __launch_bounds__(256) void block64_minmax_kernel(const Seg *segs, BatchIndex ix, int level) {
     const Seg sg = segs[blockIdx.y];
     uint32_t count = sg.n;
-    uint64_t base = sg.off;
+    const int32_t *imin = ix.ps(sg), *imax = imin;
+    int32_t *omin = ix.pmin1, *omax = ix.pmax1;
     if (level == 1) {
         count = (count + 63) / 64;
-        base = sg.off / 64;
+        imin = ix.pmin1 + sg.off / 64;
+        imax = ix.pmax1 + sg.off / 64;
+        omin = ix.pmin2;
+        omax = ix.pmax2;
     }
     if (blockIdx.x * 256 >= count) return;
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     int lo = INT_MAX, hi = INT_MIN;
     if (j < count) {
-        lo = imin[base + j];
-        hi = imax[base + j];
+        lo = imin[j];
+        hi = imax[j];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1147,8 +1149,8 @@ void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, con
     hipLaunchKernelGGL(window_index_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, ix);
     const uint32_t c0 = max_n + 1, c1 = (c0 + 63) / 64;
     dim3 g0((c0 + 255) / 256, n_segs), g1((c1 + 255) / 256, n_segs);
-    hipLaunchKernelGGL(block64_minmax_kernel, g0, dim3(256), 0, stream, d_segs, ix.ps, ix.ps, ix.pmin1, ix.pmax1, 0);
-    hipLaunchKernelGGL(block64_minmax_kernel, g1, dim3(256), 0, stream, d_segs, ix.pmin1, ix.pmax1, ix.pmin2, ix.pmax2, 1);
+    hipLaunchKernelGGL(block64_minmax_kernel, g0, dim3(256), 0, stream, d_segs, ix, 0);
+    hipLaunchKernelGGL(block64_minmax_kernel, g1, dim3(256), 0, stream, d_segs, ix, 1);
     hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.samin1, ix.samin2, 1, 1);  // samin1: lcp_kernel
 }
 

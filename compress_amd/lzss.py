@@ -91,6 +91,10 @@ class _Ctx:
         self.dict_len = n.value
         self.reserved_idx = (idx[0], idx[1])
 
+    def set_overlap(self, parts: int):
+        """run the index / match stages of this context's batches as `parts` concurrent sub-batches (tuning knob)"""
+        _check(_lib.lib().mi355_lzss_ctx_set_overlap(self.h, int(parts)))
+
     def close(self):
         if getattr(self, "h", None):
             _lib.lib().mi355_lzss_ctx_destroy(self.h)

@@ -81,6 +81,21 @@ def test_text_sizes_across_the_suffix_sort_variants(amd, dict_naive):
             assert got[k] == oc.compress(d), f"n_big={n_big} case {k}"
 
 
+def test_overlapped_sub_batches_give_the_same_bytes(amd, dict_naive):
+    """mi355_lzss_ctx_set_overlap: the stages of 2..4 sub-batches run on concurrent streams; every segment's scratch
+    (sort records, then its window index) must stay inside the segment's own region"""
+    rng = np.random.default_rng(7)
+    blobs = [amd.synth.blob(40 + k)[: int(rng.integers(1, 40000))] for k in range(70)] + [b"", bytes(30000)]
+    oc = O.Compressor(dict_naive)
+    want = [oc.compress(d) for d in blobs]
+    for parts in (1, 2, 3, 4):
+        ctx = amd.batch.new_ctx(dict_naive)
+        ctx.set_overlap(parts)
+        for _ in range(2):  # twice: the second run starts with the first one's leftovers in every buffer
+            got = amd.compress_batch(ctx, blobs)
+            assert got == want, f"parts={parts}"
+
+
 def unpack(amd_ty, amd_addr, amd_len):
     return list(zip(amd_ty.tolist(), amd_addr.tolist(), amd_len.tolist()))
 
