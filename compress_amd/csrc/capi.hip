@@ -95,7 +95,7 @@ struct mi355_lzss_ctx {
     static constexpr int kMaxSplit = 4;
     hipStream_t side[kMaxSplit] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kMaxSplit] = {};
-    int split = 1;
+    int split = 2;
 };
 
 struct mi355_lzss_batch {
