@@ -139,7 +139,7 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
     if (elems > b->cap_elems) {
         const uint64_t e = elems;
 #define R(buf, bytes_per) if ((rc = b->buf.ensure((size_t)(e * (bytes_per)))) != 0) return rc;
-        R(text, 1) R(sortA, 8) R(sortB, 8) R(rkA, 4) R(rkB, 4) R(flags, 1) R(rlen, 1)
+        R(text, 1) R(sortA, 8) R(sortB, 8) R(rlen, 1)  // rkA, rkB, flags: only with the fallback suffix sort (upload)
         R(sa, 4) R(isa, 4) R(lcp, 2) R(res, 4) R(adv, 1) R(kind, 1) R(exitoff, 1)
 #undef R
         const uint64_t e64 = e / 64 + 1, e256 = e / 256 + 1;
@@ -263,6 +263,12 @@ extern "C" int mi355_lzss_batch_upload(mi355_lzss_batch *b, const uint8_t *in, c
     }
     if ((rc = batch_reserve(b, std::max<uint32_t>(n_blobs, 1), std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
     if ((rc = b->h_stage.ensure((size_t)std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
+    if (max_n + 1 > SA_BITMAP_MAX_N) {  // the fallback suffix sort keeps ranks and boundary flags in HBM
+        const uint64_t e = b->cap_elems;
+        if ((rc = b->rkA.ensure((size_t)(e * 4))) != 0 || (rc = b->rkB.ensure((size_t)(e * 4))) != 0 ||
+            (rc = b->flags.ensure((size_t)e)) != 0)
+            return rc;
+    }
     {
         const uint64_t nch = std::max<uint32_t>(1, (max_n + LZSS_SHORT_WINDOW - 1) / LZSS_SHORT_WINDOW);
         if ((rc = b->cdir.ensure((size_t)((std::max<uint64_t>(elems, SEG_ALIGN) / 64 + 1) * nch * 2))) != 0) return rc;
