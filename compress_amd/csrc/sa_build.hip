@@ -377,6 +377,10 @@ constexpr int SA_K = SA_MAIN_K;  // sequence entries per thread and tile
 constexpr int SA_WSPAN = 64 * SA_K;            // consecutive entries of one wave inside a tile
 constexpr int SA_TILE = SAM_THREADS * SA_K;
 
+#ifndef SA_LATE_DIVISOR
+#define SA_LATE_DIVISOR 16
+#endif
+constexpr uint32_t SA_LATE_DIV = SA_LATE_DIVISOR;  // rounds with at most N / this active suffixes skip the sweep
 constexpr int SA_RUN_CAP = 254;  // runs of equal symbols are told apart by length up to here
 
 // Length of the run of equal bytes that starts at position e of the text (1 at and past its end), exact up to 257:
@@ -446,6 +450,7 @@ struct SaLds {
     int32_t *delta;    // [NB] output index minus staging index for the tile's entries of bin b
     int32_t *tpos;     // [NB] staging index of the tile's first entry of bin b
     int32_t *hl, *hh;  // [NB] digit counts of the next round's keys (low / high digit)
+    int32_t *hy;       // [NB] digit counts of a late round's second keys (high digit; the low digit's sit in tpos)
     int32_t *wtot;     // [16] tile entries per wave of bin threads
     uint16_t *whist;   // [NB][SAM_WAVES] entries of the current tile per bin and wave (zero between tiles)
     uint16_t *woff;    // [NB][SAM_WAVES] offset of wave w's entries inside the tile's bin b
@@ -458,7 +463,8 @@ struct SaLds {
         tpos = delta + NB;
         hl = tpos + NB;
         hh = hl + NB;
-        wtot = hh + NB;
+        hy = hh + NB;
+        wtot = hy + NB;
         whist = (uint16_t *)(wtot + 16);
         woff = whist + SAM_WAVES * NB;
         stage = (uint64_t *)(woff + SAM_WAVES * NB);
@@ -466,7 +472,7 @@ struct SaLds {
     }
     // words: bitmap words (even)
     static size_t bytes(uint32_t words) {
-        return (size_t)words * 4 + ((size_t)NB * 5 + 16) * 4 + (size_t)SAM_WAVES * NB * 4 + (SA_STAGE ? (size_t)SA_TILE * 8 : 0) +
+        return (size_t)words * 4 + ((size_t)NB * 6 + 16) * 4 + (size_t)SAM_WAVES * NB * 4 + (SA_STAGE ? (size_t)SA_TILE * 8 : 0) +
                (SA_MTAB ? (size_t)SAM_WAVES * mtab_entries() * 8 : 0);
     }
 };
@@ -648,6 +654,39 @@ __device__ inline void bins_scan(const int32_t *src, int32_t *base, int nb, int 
     __syncthreads();
 }
 
+// one stable scatter pass over m records by the digit (rec >> sh) & (NB - 1); `hist` holds the digit counts
+template <int DB>
+__device__ inline void scatter_pass(const SaLds<DB> &L, const uint64_t *in, uint64_t *out, uint32_t m, int sh,
+                                    const int32_t *hist, int tid) {
+    constexpr int NB = 1 << DB;
+    constexpr int MASK = NB - 1;
+    const int lane = tid & 63, w = tid >> 6;
+    bins_scan(hist, L.base, NB, tid);
+    for (uint32_t t0 = 0; t0 < m; t0 += SA_TILE) {
+        const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
+        uint64_t r[SA_K];
+        int loc[SA_K];
+#pragma unroll
+        for (int s = 0; s < SA_K; ++s) {
+            const uint32_t u = wb + s * 64 + lane;
+            r[s] = (u < m) ? in[u] : 0;
+        }
+#pragma unroll
+        for (int s = 0; s < SA_K; ++s) {
+            const uint32_t u = wb + s * 64 + lane;
+            loc[s] = tile_rank<DB, DB>(L, w, (int)(r[s] >> sh) & MASK, u < m, lane);
+        }
+        const int tile_n = tile_prepare<DB>(L, tid);
+#pragma unroll
+        for (int s = 0; s < SA_K; ++s) {
+            const uint32_t u = wb + s * 64 + lane;
+            if (u < m) tile_put<DB>(L, out, (int)(r[s] >> sh) & MASK, w, loc[s], r[s]);
+        }
+        tile_flush<DB>(L, out, sh, MASK, tile_n, tid);
+    }
+    __syncthreads();
+}
+
 // Regroup: `m` sorted records (INITIAL: (first SA_INIT_SYMS symbols, suffix) in symbol order, one group;
 // otherwise (k1, k2, suffix) sorted by (k1, sequence order)) -> slots, new group starts, bitmaps, next digit counts.
 // Returns the number of suffixes that still share their group.
@@ -800,7 +839,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
 
     SA_PROF_DECL
     for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;
-    for (int x = tid; x < 5 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh
+    for (int x = tid; x < 6 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh, hy
     for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
     if (SA_MTAB)
         for (int x = tid; x < SAM_WAVES * SaLds<DB>::mtab_entries(); x += SAM_THREADS) L.mtab[x] = 0;
@@ -901,6 +940,38 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     SA_PROF(4)
     uint32_t h = 3;  // every group of the initial keys shares at least 3 symbols
     while (m != 0 && h < N && --max_rounds >= 0) {
+        if ((uint64_t)m * SA_LATE_DIV <= N) {
+            // ---- late round: few suffixes are left, so instead of sweeping the whole suffix array the records
+            //      (k1 = RK[p], k2 = RK[p + h], p) are built straight from the `act` bitmap and sorted by (k1, k2):
+            //      four passes over m records instead of one sweep over N slots and two passes
+            int32_t *hx = L.tpos;
+            for (int x = tid; x < NB; x += SAM_THREADS) {
+                hx[x] = 0;
+                L.hy[x] = 0;
+            }
+            if (tid == 0) cy.wcount[0] = 0;
+            __syncthreads();
+            for (uint32_t x = tid; x < words; x += SAM_THREADS) {
+                uint32_t wbits = L.act[x];
+                if (wbits) {
+                    int pos = atomicAdd(&cy.wcount[0], __popc(wbits));
+                    while (wbits) {
+                        const uint32_t p = x * 32 + (uint32_t)__builtin_ctz(wbits);
+                        wbits &= wbits - 1;
+                        const uint32_t k1 = (uint32_t)rk[p];
+                        const uint32_t k2 = (p + h < N) ? (uint32_t)rk[p + h] : 0u;
+                        recB[pos++] = ((uint64_t)k1 << 40) | ((uint64_t)k2 << 20) | (uint64_t)p;
+                        atomicAdd(&hx[k2 & MASK], 1);
+                        atomicAdd(&L.hy[k2 >> DB], 1);
+                    }
+                }
+            }
+            __syncthreads();
+            scatter_pass<DB>(L, recB, recA, m, 20, hx, tid);
+            scatter_pass<DB>(L, recA, recB, m, 20 + DB, L.hy, tid);
+            scatter_pass<DB>(L, recB, recA, m, 40, L.hl, tid);
+            scatter_pass<DB>(L, recA, recB, m, 40 + DB, L.hh, tid);
+        } else {
         // ---- S1: active members of the sequence p = SA[j] - h -> records, scattered by the low digit of k1
         bins_scan(L.hl, L.base, NB, tid);
         SA_PROF(15)
@@ -978,38 +1049,11 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         }
         __syncthreads();
         // ---- S2: records by the high digit of k1
-        bins_scan(L.hh, L.base, NB, tid);
-        for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh: refilled by the regroup below
-        SA_PROF(15)
-        for (uint32_t t0 = 0; t0 < m; t0 += SA_TILE) {
-            const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
-            uint64_t r[SA_K];
-            int loc[SA_K];
-#pragma unroll
-            for (int s = 0; s < SA_K; ++s) {
-                const uint32_t u = wb + s * 64 + lane;
-                r[s] = (u < m) ? recA[u] : 0;
-            }
-            SA_PROF(10)
-#pragma unroll
-            for (int s = 0; s < SA_K; ++s) {
-                const uint32_t u = wb + s * 64 + lane;
-                loc[s] = tile_rank<DB, DB>(L, w, (int)(r[s] >> (40 + DB)) & MASK, u < m, lane);
-            }
-            SA_PROF(11)
-            const int tile_n = tile_prepare<DB>(L, tid);
-            SA_PROF(12)
-#pragma unroll
-            for (int s = 0; s < SA_K; ++s) {
-                const uint32_t u = wb + s * 64 + lane;
-                const int d = (int)(r[s] >> (40 + DB)) & MASK;
-                if (u < m) tile_put<DB>(L, recB, d, w, loc[s], r[s]);
-            }
-            tile_flush<DB>(L, recB, 40 + DB, MASK, tile_n, tid);
-            SA_PROF(13)
+        scatter_pass<DB>(L, recA, recB, m, 40 + DB, L.hh, tid);
+        SA_PROF(13)
         }
+        for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh: refilled by the regroup below
         __syncthreads();
-        SA_PROF(15)
         // ---- D: new groups
         m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid);
         SA_PROF(14)
