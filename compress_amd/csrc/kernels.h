@@ -15,7 +15,7 @@ struct SaWork {       // batch-wide arrays, indexed [seg.off + k], k in [0, n]
 };
 // texts of more than this many suffixes are sorted by the fallback kernel, which uses the sort buffers as whole-batch
 // int32 arrays: no other stage of the batch may run beside it
-constexpr uint32_t SA_BITMAP_MAX_N = 300000;
+constexpr uint32_t SA_BITMAP_MAX_N = 1u << 19;
 void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
                      hipStream_t stream);
 

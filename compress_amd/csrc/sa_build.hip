@@ -366,6 +366,7 @@ constexpr int SA_INIT_SYMS = 4;  // depth of the initial sort (symbols compared 
 #define SA_MTAB_BITS 10
 #endif
 constexpr int SA_MTB = SA_MTAB_BITS;     // digit bits resolved by the table (the rest by ballots)
+constexpr int SA_MTB_WIDE = 8;           // the same for the 10-bit-digit instantiation
 #ifndef SA_WGS_PER_CU
 #define SA_WGS_PER_CU 2
 #endif
@@ -444,7 +445,9 @@ __host__ __device__ inline uint32_t sa_bitmap_words(uint32_t N) {
 template <int DB>
 struct SaLds {
     static constexpr int NB = 1 << DB;
-    static constexpr int mtab_entries() { return 1 << (DB < SA_MTB ? DB : SA_MTB); }
+    // digit bits the peer table resolves: texts above 2^18 need a 64 KiB bitmap, their table is smaller
+    static constexpr int MTB = DB <= 9 ? SA_MTB : (SA_MTB < SA_MTB_WIDE ? SA_MTB : SA_MTB_WIDE);
+    static constexpr int mtab_entries() { return 1 << (DB < MTB ? DB : MTB); }
     uint32_t *act;     // bit p: suffix p still shares its group
     int32_t *base;     // [NB] running output index of bin b
     int32_t *delta;    // [NB] output index minus staging index for the tile's entries of bin b
@@ -485,7 +488,7 @@ struct SaCarry {
 
 // lanes of the wave (among `valid`) holding the same digit as this lane.  The most frequent digits are found
 // by two leader votes; the rest meet in the wave's bit table (one 64-bit word per digit).
-template <int RB>
+template <int RB, int MTB>
 __device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lane) {
     if (!SA_MTAB) return match_bits<RB>(d, __ballot(valid));
     uint64_t peers = 0;
@@ -506,7 +509,7 @@ __device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lan
     if (__ballot(todo)) {
         // the LDS unit executes one wave's instructions in order, so the three accesses need no waits between
         // them; the empty asm statements only keep the compiler from reordering them
-        constexpr int TB = RB < SA_MTB ? RB : SA_MTB;
+        constexpr int TB = RB < MTB ? RB : MTB;
         uint64_t *cell = mrow + (d & ((1 << TB) - 1));
         if (todo) atomicOr((unsigned long long *)cell, 1ull << lane);
         asm volatile("" ::: "memory");
@@ -528,7 +531,7 @@ __device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lan
 template <int RB, int DB>
 __device__ inline int tile_rank(const SaLds<DB> &L, int w, int d, bool valid, int lane) {
     uint16_t *cell = L.whist + d * SAM_WAVES + w;
-    const uint64_t peers = wave_peers<RB>(L.mtab + w * SaLds<DB>::mtab_entries(), d, valid, lane);
+    const uint64_t peers = wave_peers<RB, SaLds<DB>::MTB>(L.mtab + w * SaLds<DB>::mtab_entries(), d, valid, lane);
     const int cnt = __popcll(peers);
     const int rank = __popcll(peers & lanemask_lt(lane));
     const int lh = valid ? (int)*cell : 0;

@@ -46,7 +46,7 @@ const char *mi355_lzss_last_error(void);
 /* Tuning knob with no counterpart in the reference: batches of this context run their index / match stages as
  * `parts` (1..4) sub-batches on concurrent streams, so that the tail of one part's suffix sort overlaps the next
  * stages of another.  Results do not depend on it; per-stage times (batch_stage_times) are only meaningful with
- * parts == 1.  Default: 2 (batches of fewer than 8 blobs per part, or with a text above 300 000 bytes, always run as
+ * parts == 1.  Default: 2 (batches of fewer than 8 blobs per part, or with a text of 512 KiB or more, always run as
  * one part), or the environment variable MI355_LZSS_SPLIT when the context is created. */
 int  mi355_lzss_ctx_set_overlap(mi355_lzss_ctx *ctx, int parts);
 /* length of the augmented dictionary and the two reserved-symbol indices ([0]=0xFE, [1]=0xFF) */

@@ -62,11 +62,11 @@ def test_index_matches_oracle(amd):
 
 
 def test_text_sizes_across_the_suffix_sort_variants(amd, dict_naive):
-    """the suffix sort has three code paths by text size: 9-bit digits (N <= 2^18), 10-bit digits (N <= 300 000) and
-    the every-round-sorts-everything fallback above; a batch picks one by its LARGEST text, so each is exercised
-    with a ragged batch (small texts ride along) and checked on index and bytes"""
-    big = b"".join(amd.synth.blob(k) for k in range(20, 23))  # 384 KiB of calldata-like bytes
-    for n_big in (262143, 262144, 280000, 299999, 300001):
+    """the suffix sort has three code paths by text size: 9-bit digits (N <= 2^18), 10-bit digits (N <= 2^19) and the
+    every-round-sorts-everything fallback above; a batch picks one by its LARGEST text, so each is exercised with a
+    ragged batch (small texts ride along) and checked on index and bytes"""
+    big = b"".join(amd.synth.blob(k) for k in range(20, 25))  # 640 KiB of calldata-like bytes
+    for n_big in (262143, 262144, 280000, 524287, 524288):
         cases = [big[:n_big], b"", b"x", amd.synth.blob(3)[:5000], bytes(70000)]
         ctx = amd.batch.new_ctx(dict_naive)
         b = amd.batch.Batch(ctx, len(cases), sum(map(len, cases)))
