@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--blob-size", type=int, default=131072)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the streaming (config 4) sample")
     ap.add_argument("--overlap", type=int, default=2, help="concurrent sub-batches of the index / match stages")
     ap.add_argument("--stage-steps", type=int, default=2, help="extra untimed steps (one part) for the per-kernel times")
     args = ap.parse_args()
@@ -163,6 +164,22 @@ def main():
                            "achieved_GBps": round((in_bytes + int(out_total)) / (dec_ms / args.steps * 1e-3) / 1e9, 3)},
             "pcie_inclusive_MBps": round(in_bytes / (t_up + elapsed / args.steps + t_down) / 1e6, 2),
         }
+        # ---- config 4 (streaming): the Write / Revert loop vs the speculative packer on a sample
+        if world == 1 and not args.no_stream:
+            from compress_amd import stream as S
+            sdata = b"".join(blobs[:16])                      # 2 MiB of the same synthetic stream
+            comp = compress_amd.Compressor(dict_, device=local_rank)
+            t0 = time.perf_counter()
+            spec = S.pack_stream(comp, sdata, 1000, 126976)
+            t_spec = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            seq = S.pack_stream_sequential(comp, sdata[:300000], 1000, 126976)
+            t_seq = time.perf_counter() - t0
+            line["stream"] = {"workload": "config4 sample: chunks of 1000 B into blobs of <= 126976 B",
+                              "speculative_MBps": round(len(sdata) / t_spec / 1e6, 2), "speculative_bytes": len(sdata),
+                              "sequential_MBps": round(300000 / t_seq / 1e6, 3), "sequential_bytes": 300000,
+                              "blobs": len(spec),
+                              "equal_on_sequential_sample": S.pack_stream(comp, sdata[:300000], 1000, 126976) == seq}
         # ---- bit-exactness spot check + CPU baseline (oracle = checker / reported baseline only)
         if not args.no_cpu and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

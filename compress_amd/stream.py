@@ -71,9 +71,14 @@ def _speculative_one(ws: _Batches, data: bytes, i0: int, chunk: int, out_max: in
         return Header(Version, False).to_bytes() + np.packbits(allbits).tobytes(), k
 
     while True:
-        # candidate Writes j+1 .. j+lookahead (the loop starts a Write only while bytes are left)
+        # candidate Writes j+1 .. j+look (the loop starts a Write only while bytes are left).  After the first batch
+        # the blob's own bits per chunk predict where the cap falls: the next batch reaches just past that point
+        look = lookahead
+        if j and total:
+            left = (out_max - HeaderSize) * 8 - total
+            look = max(4, min(4 * lookahead, int(left / (total / j) * 1.04) + 3))
         segs, starts = [], []
-        for t in range(lookahead):
+        for t in range(look):
             s = i0 + (j + t) * chunk
             if s >= len(data):
                 break
