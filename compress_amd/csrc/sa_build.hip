@@ -325,30 +325,31 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_full_kernel(const Seg *se
 
 // ---- main kernel --------------------------------------------------------------------------------------
 // Rounds touch only the suffixes that still share their group, and every sort pass is a WORKGROUP-wide
-// stable scatter over tiles of SA_TILE sequence entries (the 16 waves rank their 64-entry steps against
-// wave-private LDS counters, one scan per tile turns them into offsets behind running per-bin bases), so a
-// pass keeps one output stream per bin and needs no counting sweep: the bin totals are known beforehand.
+// stable scatter over tiles of SA_TILE sequence entries (the waves rank their 64-entry steps against
+// per-wave LDS counters, one scan per tile turns them into offsets behind running per-bin bases), so a
+// pass keeps one output stream per bin and needs no counting sweep of its own: the bin totals are known
+// beforehand.
 //
-//   initial order: SA_INIT_SYMS LSD passes whose digit is read from the text (only the suffix numbers move);
-//                  the bin totals of every pass follow from one byte histogram of the text
+//   key sweep:     run-aware 36-bit keys (first symbol, run code, two symbols after the run) as records
+//                  (key << 20 | suffix) in text order, the run lengths (rlen) and the counts of the four digits
+//   initial order: SA_INIT_DIGITS LSD passes over the records, least significant digit first
 //   regroup (D):   boundaries of (group, second key) in the sorted records give every active suffix its slot
 //                  in the suffix array and its new group start; suffixes now alone leave the `act` bitmap;
-//                  the digits of the new group starts are counted for the next round's two passes
+//                  the digits of the new group starts are counted for the next round's passes
 //   S1:            one sweep over the suffix array: the active members of the induction sequence
 //                  p = SA[j] - h, with their group start k1 = RK[p] (the one gather of a round) and the group
-//                  start k2 of slot j (from the `gb` bitmap), packed into 8-byte records and scattered by the
-//                  low digit of k1
+//                  start k2 of slot j (the top bit of SA[j] marks the first slot of a shared group), packed
+//                  into 8-byte records and scattered by the low digit of k1
 //   S2:            scatter of the records by the high digit of k1 -> sorted by (k1, sequence order)
+//   late rounds:   when few suffixes are left, the records (RK[p], RK[p + h], p) come straight from the `act`
+//                  bitmap and are sorted by both keys (four passes over m records, no sweep over N slots)
 // Suffixes alone in their group never move again, so SA and the ranks are updated in place.
-constexpr int SA_INIT_SYMS = 4;  // depth of the initial sort (symbols compared straight from the text)
+constexpr int SA_INIT_DIGITS = 4;  // 9-bit digits of the initial keys
 #ifndef SA_MAIN_THREADS
 #define SA_MAIN_THREADS 512
 #endif
 #ifndef SA_MAIN_K
 #define SA_MAIN_K 8
-#endif
-#ifndef SA_USE_STAGE
-#define SA_USE_STAGE 0
 #endif
 #ifndef SA_USE_MTAB
 #define SA_USE_MTAB 1
@@ -371,7 +372,6 @@ constexpr int SA_MTB_WIDE = 8;           // the same for the 10-bit-digit instan
 #define SA_WGS_PER_CU 2
 #endif
 constexpr bool SA_MTAB = SA_USE_MTAB;    // lanes with equal digits find each other through a bit table in LDS
-constexpr bool SA_STAGE = SA_USE_STAGE;  // reorder every tile in LDS so that the scatter writes runs of records
 constexpr int SAM_THREADS = SA_MAIN_THREADS;
 constexpr int SAM_WAVES = SAM_THREADS / 64;
 constexpr int SA_K = SA_MAIN_K;  // sequence entries per thread and tile
@@ -415,14 +415,6 @@ __global__ __launch_bounds__(256) void rlen_kernel(const Seg *segs, const uint8_
     if (e <= sg.n) rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
 }
 
-// the first SA_INIT_SYMS symbols of suffix p (0 = sentinel, byte + 1 otherwise), 9 bits each
-__device__ inline uint64_t init_key(const uint8_t *T, uint32_t n, uint32_t p) {
-    uint64_t k = 0;
-#pragma unroll
-    for (int t = 0; t < SA_INIT_SYMS; ++t) k = (k << 9) | ((p + t < n) ? (uint64_t)T[p + t] + 1u : 0u);
-    return k;
-}
-
 template <int DB>
 __device__ inline uint64_t match_bits(int d, uint64_t amask) {
     uint64_t peers = amask;
@@ -457,7 +449,6 @@ struct SaLds {
     int32_t *wtot;     // [16] tile entries per wave of bin threads
     uint16_t *whist;   // [NB][SAM_WAVES] entries of the current tile per bin and wave (zero between tiles)
     uint16_t *woff;    // [NB][SAM_WAVES] offset of wave w's entries inside the tile's bin b
-    uint64_t *stage;   // [SA_TILE] the tile's records in bin order
     uint64_t *mtab;    // [SAM_WAVES][mtab_entries()] per wave: lanes holding (the low bits of) digit d (zero between steps)
     __device__ SaLds(uint32_t *mem, uint32_t words) {
         act = mem;
@@ -470,12 +461,11 @@ struct SaLds {
         wtot = hy + NB;
         whist = (uint16_t *)(wtot + 16);
         woff = whist + SAM_WAVES * NB;
-        stage = (uint64_t *)(woff + SAM_WAVES * NB);
-        mtab = stage + (SA_STAGE ? SA_TILE : 0);
+        mtab = (uint64_t *)(woff + SAM_WAVES * NB);
     }
     // words: bitmap words (even)
     static size_t bytes(uint32_t words) {
-        return (size_t)words * 4 + ((size_t)NB * 6 + 16) * 4 + (size_t)SAM_WAVES * NB * 4 + (SA_STAGE ? (size_t)SA_TILE * 8 : 0) +
+        return (size_t)words * 4 + ((size_t)NB * 6 + 16) * 4 + (size_t)SAM_WAVES * NB * 4 +
                (SA_MTAB ? (size_t)SAM_WAVES * mtab_entries() * 8 : 0);
     }
 };
@@ -602,27 +592,12 @@ __device__ inline int tile_prepare(const SaLds<DB> &L, int tid) {
     return total;
 }
 
-// one record of the tile: to its staging position, or straight to the output
+// one record of the tile to its place in the output: the running base of its bin + the records of the bin that
+// precede it in the tile (delta + tpos is that base; tpos alone would be its place in a tile sorted in LDS - staging
+// tiles that way so that the scatter writes whole runs was measured without gain and removed)
 template <int DB>
 __device__ inline void tile_put(const SaLds<DB> &L, uint64_t *out, int d, int w, int loc, uint64_t r) {
-    const int pos = L.tpos[d] + (int)L.woff[d * SAM_WAVES + w] + loc;
-    if (SA_STAGE) L.stage[pos] = r;
-    else out[L.delta[d] + pos] = r;
-}
-
-// the staged tile (bin order) -> out, consecutive lanes write consecutive records of a bin
-template <int DB>
-__device__ inline void tile_flush(const SaLds<DB> &L, uint64_t *out, int sh, int msk, int tile_n, int tid) {
-    if (!SA_STAGE) return;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < SA_K; ++i) {
-        const int pos = i * SAM_THREADS + tid;
-        if (pos < tile_n) {
-            const uint64_t r = L.stage[pos];
-            out[L.delta[(int)(r >> sh) & msk] + pos] = r;
-        }
-    }
+    out[L.delta[d] + L.tpos[d] + (int)L.woff[d * SAM_WAVES + w] + loc] = r;
 }
 
 // histogram update of one 64-entry step: two leader votes take the most frequent digits, the rest adds itself
@@ -679,18 +654,17 @@ __device__ inline void scatter_pass(const SaLds<DB> &L, const uint64_t *in, uint
             const uint32_t u = wb + s * 64 + lane;
             loc[s] = tile_rank<DB, DB>(L, w, (int)(r[s] >> sh) & MASK, u < m, lane);
         }
-        const int tile_n = tile_prepare<DB>(L, tid);
+        tile_prepare<DB>(L, tid);
 #pragma unroll
         for (int s = 0; s < SA_K; ++s) {
             const uint32_t u = wb + s * 64 + lane;
             if (u < m) tile_put<DB>(L, out, (int)(r[s] >> sh) & MASK, w, loc[s], r[s]);
         }
-        tile_flush<DB>(L, out, sh, MASK, tile_n, tid);
     }
     __syncthreads();
 }
 
-// Regroup: `m` sorted records (INITIAL: (first SA_INIT_SYMS symbols, suffix) in symbol order, one group;
+// Regroup: `m` sorted records (INITIAL: (initial key, suffix) in key order, one group;
 // otherwise (k1, k2, suffix) sorted by (k1, sequence order)) -> slots, new group starts, bitmaps, next digit counts.
 // Returns the number of suffixes that still share their group.
 template <bool INITIAL, int DB>
@@ -889,7 +863,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     {
         const uint64_t *rin = recB;
         uint64_t *rout = recA;
-        for (int pass = 0; pass < SA_INIT_SYMS; ++pass) {
+        for (int pass = 0; pass < SA_INIT_DIGITS; ++pass) {
             const int shift = 20 + 9 * pass;
             bins_scan(pass == 0 ? hY : pass == 1 ? hX : pass == 2 ? hC : hS, L.base, NB, tid);
             SA_PROF(15)
@@ -917,7 +891,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
 #pragma unroll
                     for (int s = 0; s < SA_K; ++s) nx[s] = load_rec(wb + SA_TILE + s * 64 + lane);
                 }
-                const int tile_n = tile_prepare<DB>(L, tid);
+                tile_prepare<DB>(L, tid);
                 SA_PROF(2)
 #pragma unroll
                 for (int s = 0; s < SA_K; ++s) {
@@ -925,7 +899,6 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     const int sym = (int)(r[s] >> shift) & 511;
                     if (e < N) tile_put<DB>(L, rout, sym, w, loc[s], r[s]);
                 }
-                tile_flush<DB>(L, rout, shift, 511, tile_n, tid);
                 SA_PROF(3)
             }
             __syncthreads();
@@ -933,7 +906,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             rout = (rout == recA) ? recB : recA;
         }
     }
-    const uint64_t *rcur = (SA_INIT_SYMS & 1) ? recA : recB;
+    const uint64_t *rcur = (SA_INIT_DIGITS & 1) ? recA : recB;
     for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh
     for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;  // held two digit histograms so far
     __syncthreads();
@@ -1029,7 +1002,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                 }
                 if (lane == 0) cy.a[par][w] = runG;
                 SA_PROF(7)
-                const int tile_n = tile_prepare<DB>(L, tid);
+                tile_prepare<DB>(L, tid);
                 SA_PROF(8)
                 int cin = tileG;
                 for (int ww = 0; ww < SAM_WAVES; ++ww) {
@@ -1046,7 +1019,6 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                                      ((uint64_t)(uint32_t)k1[s] << 40) | ((uint64_t)(uint32_t)g << 20) | (uint64_t)(uint32_t)p[s]);
                     }
                 }
-                tile_flush<DB>(L, recA, 40, MASK, tile_n, tid);
                 SA_PROF(9)
             }
         }
