@@ -9,3 +9,4 @@ from .lzss import (  # noqa: F401
     Compressor, NewCompressor, AugmentDict, Decompress, Header, LzssError,
     compress_batch, decompress_batch,
 )
+from .info import CompressionPhrase, CompressedStreamInfo, ToCSV  # noqa: F401,E402

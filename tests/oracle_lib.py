@@ -205,3 +205,72 @@ def decompress(data: bytes, dict_: bytes = b"") -> bytes:
         return C.string_at(out.value, out_len.value)
     finally:
         lib().ora_free(out)
+
+
+def compressed_stream_info(c: bytes, dict_: bytes = b""):
+    """Literal transcription of CompressedStreamInfo (lzss/decompress.go:97-206) in plain Python (test
+    infrastructure, small cases only): byte-at-a-time copying into `out` (which starts with the augmented
+    dictionary), literals grouped, StartCompressed in bits after the header.  Returns a list of tuples
+    (type, length, reference_address, start_decompressed, start_compressed, content)."""
+    c = bytes(c)
+    if len(c) < 3:
+        raise OracleError("failed to read header")
+    version, noc = (c[0] << 8) | c[1], c[2]
+    if version != 1:
+        raise OracleError("unsupported compressor version")
+    if noc == 1:                                   # decompress.go:109-118
+        return [(0, len(c) - 3, 0, 0, 0, c[3:])]
+    out = bytearray(augment_dict(dict_))            # decompress.go:123-132
+    res = []
+    bits = "".join(format(b, "08b") for b in c[3:])
+    pos = 0
+    err = False
+
+    def read(n):                                    # bitio TryReadBits: sets the error at EOF
+        nonlocal pos, err
+        if err or pos + n > len(bits):
+            err = True
+            return 0
+        v = int(bits[pos:pos + n], 2)
+        pos += n
+        return v
+
+    lit_start, in_i = -1, 0
+
+    def emit_literal():                             # decompress.go:141-155
+        nonlocal lit_start, in_i
+        if lit_start == -1:
+            return
+        res.append((0, len(out) - lit_start, lit_start, lit_start, in_i, bytes(out[lit_start:])))
+        in_i += (len(out) - lit_start) * 8
+        lit_start = -1
+
+    s = read(8)
+    while not err:                                  # decompress.go:172-203
+        if s == 0xFE or s == 0xFF:
+            emit_literal()
+            abits = 14 if s == 0xFE else 21
+            length = read(8) + 1
+            address = read(abits) + 1
+            if err:
+                raise OracleError("EOF")
+            for _ in range(length):
+                out.append(out[len(out) - address])
+            res.append((s, length, len(out) - length - address, len(out) - length, in_i, bytes(out[len(out) - length:])))
+            in_i += 8 + 8 + abits
+        else:
+            if lit_start == -1:
+                lit_start = len(out)
+            out.append(s)
+        s = read(8)
+    emit_literal()
+    return res
+
+
+def to_csv(phrases) -> bytes:
+    """CompressionPhrases.ToCSV (lzss/decompress.go:208-236)"""
+    b = "type,length,start_decompressed (bytes),start_compressed (bits),reference_address,content (hex)\n"
+    for ty, length, ref, sd, sc, content in phrases:
+        b += {0xFE: "short,", 0xFF: "long,", 0: "literal,"}[ty]
+        b += f"{length},{sd},{sc},{ref},{content.hex()}\n"
+    return b.encode()
