@@ -69,6 +69,8 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, Batch
             l = (uint32_t)lcp_run(T, RL, a, b, lim);
         }
         ix.lcp[sg.off + k] = (uint16_t)l;
+        if (k == N - 1)  // the upward walk of match_kernel reads up to three ranks past N and must die there
+            for (uint32_t e = 0; e < 4; ++e) ix.lcp[sg.off + N + e] = 0;
     }
     // minimum of LCP and of SA over the 64 ranks of this wave
     uint32_t m = l;
@@ -415,6 +417,20 @@ __device__ inline bool never_queried(const uint8_t *RL, int i) {
 #endif
 constexpr int SCAN_CAP = MATCH_SCAN_CAP;  // x4 ranks a lane walks alone before its wave takes the walk over
 
+__device__ inline uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t t = a < b ? a : b;
+    return t < c ? t : c;
+}
+__device__ inline uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t t = a > b ? a : b;
+    return t > c ? t : c;
+}
+
+#ifndef MATCH_COOP_THR
+#define MATCH_COOP_THR 0
+#endif
+constexpr int COOP_THR = MATCH_COOP_THR;  // lanes still walking at or below which the wave takes their walks over early
+
 __device__ inline int wave_incl_min(int v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -464,52 +480,52 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     const int wsL = i > LZSS_DYN_WINDOW ? i - LZSS_DYN_WINDOW : 0;
     const bool scan = work && shortOK && !(ablate & 4);
 
-    int LupS = 0, pupS = -1, LupL = 0, pupL = -1;
-    int LdnS = 0, kdnS = -1, LdnL = 0, kdnL = -1;
+    // nearest in-window neighbour per side and window as one word, rank << 9 | lcp with it (lcp <= 256, rank <= 2^22):
+    // walking up the nearest is the smallest such word, walking down the largest, so a rank costs one min / max per
+    // window instead of a chain of mask operations on the scalar unit
+    constexpr uint32_t NONE_UP = 0xFFFFFFFFu, NONE_DN = 0u;
+    uint32_t qupS = NONE_UP, qupL = NONE_UP, qdnS = NONE_DN, qdnL = NONE_DN;
+    // p lies in a window <=> (uint)(i - 1 - p) < span.  A walk does not test whether it is still alive (running lcp
+    // >= minS) rank by rank: the lcp never grows along a walk, so the first in-window rank is found regardless and a
+    // dead one carries an lcp below the minimum, which the length selection further down discards anyway
+    const uint32_t im1 = (uint32_t)(i - 1), spanS = (uint32_t)(i - wsS), spanL = (uint32_t)(i - wsL);
 
     MP(0)
-    // ---- nearest in-window neighbours above r (the arrays are padded past N)
+    // ---- nearest in-window neighbours above r (LCP is zero for four ranks past N: the walk dies there)
     {
         int m = 1 << 20, k = r + 1;
-        bool fL = false, done = !scan || k >= N;
-        // written with selects, not branches: the scalar unit (exec-mask bookkeeping) is this kernel's scarcest resource
-        for (int it = 0; it < SCAN_CAP && __ballot(!done); ++it) {
+        bool done = !scan || k >= N;
+        for (int it = 0; it < SCAN_CAP && __popcll(__ballot(!done)) > COOP_THR; ++it) {
             I4 sa4;
             U4 l4;
-            sa4.v = 0x7FFFFFFF;
-            l4.v = 0;
+            sa4.v = 0x7FFFFFFF;  // lanes that have finished see ranks outside every window whose lcp changes nothing
+            l4.v = 0xFFFF;
             if (!done) {
                 sa4 = ld_i4(SA + k);
                 l4 = ld_u4(LCP + k);
             }
+            uint32_t cS[4], cL[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int l = l4.v[t];
-                const int mm = l < m ? l : m;
-                const bool live = !done && (k + t < N);
-                const int p = sa4.v[t];
-                const bool cand = live && mm >= minS && p < i;
-                const bool hL = cand && !fL && p >= wsL;
-                const bool hS = cand && p >= wsS;
-                LupL = hL ? mm : LupL;
-                pupL = hL ? p : pupL;
-                fL = fL || hL;
-                LupS = hS ? mm : LupS;
-                pupS = hS ? p : pupS;
-                m = live ? mm : m;
-                done = done || !live || mm < minS || hS;
+                m = l < m ? l : m;
+                const uint32_t d = im1 - (uint32_t)sa4.v[t];  // offset - 1; wraps to >= 2^31 for positions >= i
+                const uint32_t key = ((uint32_t)(k + t) << 9) | (uint32_t)m;
+                cS[t] = d < spanS ? key : NONE_UP;
+                cL[t] = d < spanL ? key : NONE_UP;
             }
+            qupS = min3u(qupS, min3u(cS[0], cS[1], cS[2]), cS[3]);
+            qupL = min3u(qupL, min3u(cL[0], cL[1], cL[2]), cL[3]);
+            done = done || m < minS || qupS != NONE_UP || k + 4 >= N;
             k = done ? k : k + 4;
         }
-        if (k >= N) done = true;
         MP(1)
         for (uint64_t hm = __ballot(!done); hm; hm &= hm - 1) {  // the wave finishes lane t's walk
             const int t = (int)__builtin_ctzll(hm);
             const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
             int cm = __shfl(m, t);
-            bool cfL = __shfl((int)fL, t) != 0;
-            int rLL = 0, rpL = -1, rLS = 0, rpS = -1;
-            bool gotL = false;
+            bool cfL = __shfl((int)(qupL != NONE_UP), t) != 0;
+            uint32_t rL = NONE_UP, rS = NONE_UP;
             for (int base = __shfl(k, t); base < N; base += 64) {
                 const int kk = base + lane;
                 const bool valid = kk < N;
@@ -523,20 +539,20 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
                 const uint64_t bDead = __ballot(!alive);
                 if (!cfL && bL) {
                     const int t2 = (int)__builtin_ctzll(bL);
-                    rLL = __shfl(pm, t2); rpL = __shfl(p, t2);
-                    cfL = true; gotL = true;
+                    rL = ((uint32_t)(base + t2) << 9) | (uint32_t)__shfl(pm, t2);
+                    cfL = true;
                 }
                 if (bS) {
                     const int t2 = (int)__builtin_ctzll(bS);
-                    rLS = __shfl(pm, t2); rpS = __shfl(p, t2);
+                    rS = ((uint32_t)(base + t2) << 9) | (uint32_t)__shfl(pm, t2);
                     break;
                 }
                 if (bDead) break;
                 cm = __shfl(pm, 63);
             }
             if (lane == t) {
-                if (gotL) { LupL = rLL; pupL = rpL; }
-                LupS = rLS; pupS = rpS;
+                if (rL != NONE_UP) qupL = rL;
+                qupS = rS;
             }
         }
     }
@@ -544,48 +560,43 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     // ---- nearest in-window neighbours below r: lcp(i, SA[k]) = min LCP[k+1 .. r]; rank 0 is the sentinel
     {
         int m = 1 << 20, k = r - 1;
-        bool fL = false, done = !scan;
-        for (int it = 0; it < SCAN_CAP && __ballot(!done && k >= 4); ++it) {  // ranks k, k-1, k-2, k-3
+        bool done = !scan;
+        for (int it = 0; it < SCAN_CAP && __popcll(__ballot(!done && k >= 4)) > COOP_THR; ++it) {  // ranks k, k-1, k-2, k-3
             const bool go = !done && k >= 4;
             I4 sa4;
             U4 l4;
             sa4.v = 0x7FFFFFFF;
-            l4.v = 0;
+            l4.v = 0xFFFF;
             if (go) {
                 sa4 = ld_i4(SA + k - 3);
                 l4 = ld_u4(LCP + k - 2);
             }
-            bool stop = !go;
+            uint32_t cS[4], cL[4];
 #pragma unroll
             for (int t = 3; t >= 0; --t) {
                 const int l = l4.v[t];
-                const int mm = l < m ? l : m;
-                const bool live = !stop;
-                const int p = sa4.v[t];
-                const bool cand = live && mm >= minS && p < i;
-                const bool hL = cand && !fL && p >= wsL;
-                const bool hS = cand && p >= wsS;
-                const int kk = k - 3 + t;
-                LdnL = hL ? mm : LdnL;
-                kdnL = hL ? kk : kdnL;
-                fL = fL || hL;
-                LdnS = hS ? mm : LdnS;
-                kdnS = hS ? kk : kdnS;
-                m = live ? mm : m;
-                stop = stop || mm < minS || hS;
+                m = l < m ? l : m;
+                const uint32_t d = im1 - (uint32_t)sa4.v[t];
+                const uint32_t key = ((uint32_t)(k - 3 + t) << 9) | (uint32_t)m;
+                cS[t] = d < spanS ? key : NONE_DN;
+                cL[t] = d < spanL ? key : NONE_DN;
             }
+            qdnS = max3u(qdnS, max3u(cS[0], cS[1], cS[2]), cS[3]);
+            qdnL = max3u(qdnL, max3u(cL[0], cL[1], cL[2]), cL[3]);
+            const bool stop = m < minS || qdnS != NONE_DN;
             done = done || (go && stop);
             k = (go && !stop) ? k - 4 : k;
         }
         if (!done && k < 4) {
-            for (; k >= 1 && !done; --k) {
+            for (; k >= 1; --k) {
                 const int l = LCP[k + 1];
                 m = l < m ? l : m;
                 if (m < minS) break;
                 const int p = SA[k];
                 if (p < i) {
-                    if (!fL && p >= wsL) { fL = true; LdnL = m; kdnL = k; }
-                    if (p >= wsS) { LdnS = m; kdnS = k; break; }
+                    const uint32_t key = ((uint32_t)k << 9) | (uint32_t)m;
+                    if (qdnL == NONE_DN && p >= wsL) qdnL = key;
+                    if (p >= wsS) { qdnS = key; break; }
                 }
             }
             done = true;
@@ -595,9 +606,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
             const int t = (int)__builtin_ctzll(hm);
             const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
             int cm = __shfl(m, t);
-            bool cfL = __shfl((int)fL, t) != 0;
-            int rLL = 0, rkL = -1, rLS = 0, rkS = -1;
-            bool gotL = false;
+            bool cfL = __shfl((int)(qdnL != NONE_DN), t) != 0;
+            uint32_t rL = NONE_DN, rS = NONE_DN;
             for (int base = __shfl(k, t); base >= 1; base -= 64) {
                 const int kk = base - lane;
                 const bool valid = kk >= 1;
@@ -611,23 +621,27 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
                 const uint64_t bDead = __ballot(!alive);
                 if (!cfL && bL) {
                     const int t2 = (int)__builtin_ctzll(bL);
-                    rLL = __shfl(pm, t2); rkL = base - t2;
-                    cfL = true; gotL = true;
+                    rL = ((uint32_t)(base - t2) << 9) | (uint32_t)__shfl(pm, t2);
+                    cfL = true;
                 }
                 if (bS) {
                     const int t2 = (int)__builtin_ctzll(bS);
-                    rLS = __shfl(pm, t2); rkS = base - t2;
+                    rS = ((uint32_t)(base - t2) << 9) | (uint32_t)__shfl(pm, t2);
                     break;
                 }
                 if (bDead) break;
                 cm = __shfl(pm, 63);
             }
             if (lane == t) {
-                if (gotL) { LdnL = rLL; kdnL = rkL; }
-                LdnS = rLS; kdnS = rkS;
+                if (rL != NONE_DN) qdnL = rL;
+                qdnS = rS;
             }
         }
     }
+    const int LupS = qupS != NONE_UP ? (int)(qupS & 511u) : 0, kupS = (int)(qupS >> 9);
+    const int LupL = qupL != NONE_UP ? (int)(qupL & 511u) : 0, kupL = (int)(qupL >> 9);
+    const int LdnS = (int)(qdnS & 511u), kdnS = (int)(qdnS >> 9);
+    const int LdnL = (int)(qdnL & 511u), kdnL = (int)(qdnL >> 9);
     MP(4)
     SegIndex S;
     S.SA = SA; S.LCP = LCP; S.b1 = b1; S.b2 = b2;
@@ -667,7 +681,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     if (short_wins || long_wins) {
         const bool up = short_wins ? upS : upL;
         const int kdn = short_wins ? kdnS : kdnL;
-        if (up) p = short_wins ? pupS : pupL;
+        if (up) p = SA[short_wins ? kupS : kupL];
         else if (ablate & 2) p = SA[kdn];
         else p = leftmost(S, kdn, short_wins ? Ls : LL, short_wins ? wsS : wsL, i, short_wins MP_PASS);
     }
