@@ -14,6 +14,7 @@
 //   emit_kernel     every tile packs its phrases into bytes; the two partial bytes at a tile's ends are
 //                   merged with the neighbours' after a barrier (no atomics).
 #include "kernels.h"
+#include "window_search.h"
 
 namespace lzss {
 
@@ -261,8 +262,17 @@ struct BitSink {
     }
 };
 
+// address bits of a result match_kernel left pending: the smallest-rank occurrence of the match inside the window
+// (compress.go:444: windowStart = max(0, i - maxAddress)), searched from the rank stored in the field
+__device__ inline uint32_t resolve_field(const SegIndex &S, uint32_t r, int i, bool is_short) {
+    const int span = is_short ? LZSS_SHORT_WINDOW : LZSS_DYN_WINDOW;
+    const int ws = i > span ? i - span : 0;
+    const int p = leftmost(S, (int)res_field(r), (int)res_len(r), ws, i, is_short);
+    return (uint32_t)(i - p - 1);
+}
+
 __global__ __launch_bounds__(WALK_THREADS) void emit_kernel(const Seg *segs, const uint8_t *text, const uint32_t *res,
-                                                            WalkWork ww, uint32_t header_bytes, uint32_t bit_off,
+                                                            BatchIndex ix, WalkWork ww, uint32_t header_bytes, uint32_t bit_off,
                                                             uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                                                             uint8_t *out_buf, uint64_t out_cap, int32_t *status) {
     const Seg sg = segs[blockIdx.x];
@@ -277,6 +287,7 @@ __global__ __launch_bounds__(WALK_THREADS) void emit_kernel(const Seg *segs, con
     if (tid == 0) status[blockIdx.x] = 0;
     const uint8_t *T = text + sg.off;
     const uint32_t *R = res + sg.off;
+    const SegIndex S = seg_index(ix, sg);
     const uint8_t *adv = ww.adv + sg.off;
     const uint8_t *kind = ww.kind + sg.off;
     const uint16_t *entry = ww.entry + sg.off / TILE;
@@ -318,13 +329,14 @@ __global__ __launch_bounds__(WALK_THREADS) void emit_kernel(const Seg *segs, con
                 case K_LIT2: s.put(((uint64_t)T[i] << 8) | T[i + 1], 16); break;
                 case K_SHORT: {
                     const uint32_t r = R[i];
-                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(res_len(r) - 1) << 14) | (res_field(r) & 0x3FFFu),
-                          LZSS_SHORT_BITS);
+                    const uint32_t f = res_pending(r) ? resolve_field(S, r, i, true) : res_field(r);
+                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(res_len(r) - 1) << 14) | (f & 0x3FFFu), LZSS_SHORT_BITS);
                     break;
                 }
                 case K_DYN: {
                     const uint32_t r = R[i];
-                    s.put(((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | ((uint64_t)(res_len(r) - 1) << 21) | res_field(r), LZSS_DYN_BITS);
+                    const uint32_t f = res_pending(r) ? resolve_field(S, r, i, false) : res_field(r);
+                    s.put(((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | ((uint64_t)(res_len(r) - 1) << 21) | f, LZSS_DYN_BITS);
                     break;
                 }
                 case K_RLE_CONT:  // short ref at address i-1, length count (compress.go:209-212)
@@ -365,11 +377,12 @@ __global__ __launch_bounds__(WALK_THREADS) void emit_kernel(const Seg *segs, con
     }
 }
 
-void launch_emit(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const uint32_t *d_res, const WalkWork &ww,
+void launch_emit(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const uint32_t *d_res, const BatchIndex &ix,
+                 const WalkWork &ww,
                  uint32_t header_bytes, uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                  uint8_t *d_out, uint64_t out_cap, int32_t *d_status, hipStream_t stream) {
     if (n_segs == 0) return;
-    hipLaunchKernelGGL(emit_kernel, dim3(n_segs), dim3(WALK_THREADS), 0, stream, d_segs, d_text, d_res, ww, header_bytes,
+    hipLaunchKernelGGL(emit_kernel, dim3(n_segs), dim3(WALK_THREADS), 0, stream, d_segs, d_text, d_res, ix, ww, header_bytes,
                        bit_off, dict_len, res_idx_fe, res_idx_ff, d_out, out_cap, d_status);
 }
 

@@ -33,11 +33,17 @@ constexpr int HEAD = LZSS_HEAD;         // positions below HEAD are matched by b
 constexpr uint32_t RES_NONE = 0u;
 constexpr uint32_t RES_SHORT = 1u;
 constexpr uint32_t RES_DYN = 2u;
+// type:2 | pending:1 | length-1:8 | field:21.  field = the address bits as written (backref.go:66), or, while the
+// result is PENDING, the rank the search for the smallest-rank occurrence starts from (window_search.h): emit_kernel
+// finishes pending results for the phrases it writes.  Ranks need 21 bits, so only texts below 2 MiB are deferred.
+constexpr uint32_t RES_PENDING = 1u << 29;
+constexpr uint32_t RES_DEFER_MAX_N = 1u << 21;  // N = n + 1 must stay below
 __host__ __device__ inline uint32_t res_pack(uint32_t type, uint32_t len, uint32_t field) {
-    return (type << 30) | (len << 21) | (field & 0x1FFFFFu);
+    return type == RES_NONE ? 0u : (type << 30) | (((len - 1u) & 0xFFu) << 21) | (field & 0x1FFFFFu);
 }
 __host__ __device__ inline uint32_t res_type(uint32_t r) { return r >> 30; }
-__host__ __device__ inline uint32_t res_len(uint32_t r) { return (r >> 21) & 0x1FFu; }
+__host__ __device__ inline uint32_t res_len(uint32_t r) { return (r >> 30) ? ((r >> 21) & 0xFFu) + 1u : 0u; }
+__host__ __device__ inline bool res_pending(uint32_t r) { return (r & RES_PENDING) != 0; }
 __host__ __device__ inline uint32_t res_field(uint32_t r) { return r & 0x1FFFFFu; }
 
 // phrase kinds chosen by the walk (compress.go:176-257)

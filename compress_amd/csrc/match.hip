@@ -25,10 +25,8 @@
 
 #include "kernels.h"
 
-namespace lzss {
-
 #ifdef MATCH_PROFILE  // per-section clocks summed over all waves (debug builds only)
-__device__ unsigned long long g_mp[16];
+namespace lzss { __device__ unsigned long long g_mp[16]; }
 #define MP_DECL long long mp_acc[15] = {}; long long mp_last = clock64();
 #define MP(i) { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); mp_acc[i] += t_ - mp_last; mp_last = t_; }
 #define MP_PRINT if (threadIdx.x == 0 && (blockIdx.x & 31) == 0) { for (int q_ = 0; q_ < 15; ++q_) atomicAdd(&g_mp[q_], (unsigned long long)mp_acc[q_]); atomicAdd(&g_mp[15], 1ull); }
@@ -41,6 +39,10 @@ __device__ unsigned long long g_mp[16];
 #define MP_ARG
 #define MP_PASS
 #endif
+#include "window_search.h"
+
+namespace lzss {
+
 constexpr int LCP_THREADS = 256;
 #ifndef MATCH_BLOCK
 #define MATCH_BLOCK 64
@@ -280,132 +282,6 @@ __device__ inline uint32_t select_backref(const DictView &D, int i, int minD, bo
     return res_pack(RES_NONE, 0, 0);
 }
 
-// first j in [j0, end) with P[j] < x (LESS) or P[j] >= x (!LESS); `end` if there is none.  m1 / m2 hold the
-// min (LESS) or max (!LESS) of P over blocks of 64 and 4096 entries, so whole blocks without a hit are
-// skipped: at most ~64 steps per level whatever the distance.
-template <bool LESS>
-__device__ inline int next_thr(const int32_t *P, const int32_t *m1, const int32_t *m2, int j0, int end, int x) {
-    int j = j0;
-    // rest of the current 64-block, four entries per load once j is a multiple of 4
-    while (j < end && (j & 3)) {
-        const int v = P[j];
-        if (LESS ? v < x : v >= x) return j;
-        ++j;
-    }
-    while (j < end && (j & 63)) {
-        const I4 q = ld_i4(P + j);  // entries past `end` belong to the padded allocation and are ignored
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (j + t < end && (LESS ? q.v[t] < x : q.v[t] >= x)) return j + t;
-        j += 4;
-    }
-    if (j >= end) return end;
-    int b = j >> 6;
-    const int bend = (end + 63) >> 6;
-    while (b < bend) {
-        if ((b & 63) == 0) {
-            const int v2 = m2[b >> 6];
-            if (LESS ? v2 >= x : v2 < x) { b += 64; continue; }
-        }
-        if ((b & 3) == 0 && b + 4 <= bend) {  // four block summaries per load
-            const I4 q = ld_i4(m1 + b);
-            int t = 0;
-            for (; t < 4; ++t)
-                if (LESS ? q.v[t] < x : q.v[t] >= x) break;
-            b += t;
-            if (t < 4) break;
-            continue;
-        }
-        const int v1 = m1[b];
-        if (LESS ? v1 < x : v1 >= x) break;
-        ++b;
-    }
-    if (b >= bend) return end;
-    for (j = b << 6; j < end; j += 4) {
-        const I4 q = ld_i4(P + j);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (j + t < end && (LESS ? q.v[t] < x : q.v[t] >= x)) return j + t;
-    }
-    return end;
-}
-
-struct SegIndex {  // one segment's view of BatchIndex
-    const int32_t *SA;
-    const uint16_t *LCP, *b1, *b2;
-    const int32_t *KS, *PS, *pmin1, *pmax1, *pmin2, *pmax2, *samin1, *samin2;
-    const uint16_t *cdir;
-    int nch;
-    int n;
-};
-
-#ifndef MATCH_LINEAR_SPAN
-#define MATCH_LINEAR_SPAN 24
-#endif
-constexpr int LINEAR_SPAN = MATCH_LINEAR_SPAN;  // intervals up to this many ranks are scanned directly
-
-// first entry j in [a, end) of a chunk's rank-ordered list with KS[j] >= lo, a coming from the chunk directory
-// (so at most 64 entries away, a chunk's share of 64 ranks)
-__device__ inline int chunk_lower_bound(const int32_t *KS, int a, int end, int lo) {
-    while (a < end && (a & 3)) {
-        if (KS[a] >= lo) return a;
-        ++a;
-    }
-    while (a < end) {
-        const I4 q = ld_i4(KS + a);  // entries past `end` belong to the padded allocation and are ignored
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (a + t >= end || q.v[t] >= lo) return (a + t < end) ? a + t : end;
-        a += 4;
-    }
-    return end;
-}
-
-// Smallest-rank occurrence inside the window [ws, i) among the suffixes sharing >= L bytes with rank kdn (which is
-// itself in the window, so the answer is <= kdn).  SHORT window: through the window index (two chunks, one-sided
-// condition in each).  LONG window: ws == 0 whenever i <= 2^21, and then "pos < i" over the suffix array itself is
-// one-sided.  A lane needs this for ONE of its two windows only (the one whose reference is emitted), so both share
-// the interval search.
-__device__ inline int leftmost(const SegIndex &S, int kdn, int L, int ws, int i, bool is_short MP_ARG) {
-    const int lo = prev_lower(S.LCP, S.b1, S.b2, kdn, L);
-    MP(8)
-    int res = -1;
-    if (kdn - lo <= LINEAR_SPAN || (!is_short && ws != 0)) {
-        for (int k = lo; k < kdn && res < 0; ++k) {
-            const int p = S.SA[k];
-            if (p >= ws && p < i) res = p;
-        }
-        if (res < 0) res = S.SA[kdn];
-        MP(9)
-    } else if (is_short) {
-        int best = kdn;
-        const int c2 = (i - 1) >> LZSS_SHORT_ADDR_BITS;  // chunk of the window's last position: entries with pos < i
-        const int lo1 = lo < 1 ? 1 : lo;                 // rank 0 is the sentinel, in no chunk
-        const uint16_t *dir = S.cdir + (size_t)((lo1 - 1) >> 6) * S.nch;
-        {
-            const int beg = c2 << LZSS_SHORT_ADDR_BITS;
-            const int end = (beg + LZSS_SHORT_WINDOW) < S.n ? (beg + LZSS_SHORT_WINDOW) : S.n;
-            const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2], end, lo1);
-            const int j = next_thr<true>(S.PS, S.pmin1, S.pmin2, a, end, i);
-            if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
-        }
-        if (c2 >= 1 && ws < (c2 << LZSS_SHORT_ADDR_BITS)) {  // previous chunk: entries with pos >= ws
-            const int beg = (c2 - 1) << LZSS_SHORT_ADDR_BITS;
-            const int end = beg + LZSS_SHORT_WINDOW;
-            const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2 - 1], end, lo1);
-            const int j = next_thr<false>(S.PS, S.pmax1, S.pmax2, a, end, ws);
-            if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
-        }
-        res = S.SA[best];
-        MP(10)
-    } else {
-        const int k = next_thr<true>(S.SA, S.samin1, S.samin2, lo, kdn + 1, i);
-        res = S.SA[k <= kdn ? k : kdn];
-        MP(11)
-    }
-    return res;
-}
-
 // true when the walk can never call bestBackref(i): i, i-1 and i-2 lie in one run of equal bytes and at
 // least 160 of them follow i, so the RLE branch (compress.go:184) is taken at i, i-1 and i-2
 __device__ inline bool never_queried(const uint8_t *RL, int i) {
@@ -444,7 +320,7 @@ __device__ inline int wave_incl_min(int v, int lane) {
 // for a few (heavy tail), so a lane walks SCAN_CAP x 4 ranks alone; whatever is left is finished by the
 // whole wave, 64 ranks per step (coalesced loads, prefix-min of LCP across lanes, ballot for the first hit).
 __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, BatchIndex ix,
-                                                              DictView D, uint32_t *res, int skip_unqueried, int ablate) {
+                                                              DictView D, uint32_t *res, int skip_unqueried, int defer, int ablate) {
     const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);
     if (vb >= gx * n_segs) return;
     const uint32_t bx = vb % gx;
@@ -458,8 +334,6 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     const uint8_t *T = ix.text + sg.off;
     const int32_t *SA = ix.sa + sg.off;
     const uint16_t *LCP = ix.lcp + sg.off;
-    const uint16_t *b1 = ix.bmin1 + sg.off / 64;
-    const uint16_t *b2 = ix.bmin2 + sg.off / 64;
 
     bool work = r >= 1 && r < N;
     int i = 0;
@@ -643,14 +517,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     const int LdnS = (int)(qdnS & 511u), kdnS = (int)(qdnS >> 9);
     const int LdnL = (int)(qdnL & 511u), kdnL = (int)(qdnL >> 9);
     MP(4)
-    SegIndex S;
-    S.SA = SA; S.LCP = LCP; S.b1 = b1; S.b2 = b2;
-    S.KS = ix.ks(sg); S.PS = ix.ps(sg);
-    S.pmin1 = ix.pmin1 + sg.off / 64; S.pmax1 = ix.pmax1 + sg.off / 64;
-    S.pmin2 = ix.pmin2 + sg.off / 64; S.pmax2 = ix.pmax2 + sg.off / 64;
-    S.samin1 = ix.samin1 + sg.off / 64; S.samin2 = ix.samin2 + sg.off / 64;
-    S.cdir = ix.cdir + (sg.off / 64) * ix.nch; S.nch = (int)ix.nch;
-    S.n = n;
+    const SegIndex S = seg_index(ix, sg);
     // lengths in both windows (compress.go:146-159)
     int Ls = 0, LL = 0;
     bool upS = false, upL = false;  // the upper neighbour alone attains the length: it IS the smallest-rank occurrence
@@ -677,11 +544,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     const int Ldyn = dynOK ? (from_dict ? Ld : LL) : 0;
     const bool short_wins = work && Ls > 0 && Ls >= Ldyn;   // 8*Ls-30 > 8*Ldyn-37 (compress.go:165)
     const bool long_wins = work && !short_wins && Ldyn > 0 && !from_dict;
+    // the smallest-rank occurrence (the address bits).  When the lower neighbour attains the length it takes an
+    // interval search; with `defer` that is left to emit_kernel, which runs it for the phrases it writes only
     int p = -1;
+    bool pending = false;
     if (short_wins || long_wins) {
         const bool up = short_wins ? upS : upL;
         const int kdn = short_wins ? kdnS : kdnL;
         if (up) p = SA[short_wins ? kupS : kupL];
+        else if (defer) { pending = true; p = kdn; }
         else if (ablate & 2) p = SA[kdn];
         else p = leftmost(S, kdn, short_wins ? Ls : LL, short_wins ? wsS : wsL, i, short_wins MP_PASS);
     }
@@ -689,7 +560,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     MP_PRINT
     if (!work) return;
     uint32_t out = res_pack(RES_NONE, 0, 0);
-    if (short_wins) out = res_pack(RES_SHORT, (uint32_t)Ls, (uint32_t)(i - p - 1));
+    if (pending) out = res_pack(short_wins ? RES_SHORT : RES_DYN, (uint32_t)(short_wins ? Ls : LL), (uint32_t)p) | RES_PENDING;
+    else if (short_wins) out = res_pack(RES_SHORT, (uint32_t)Ls, (uint32_t)(i - p - 1));
     else if (long_wins) out = res_pack(RES_DYN, (uint32_t)LL, (uint32_t)(i - p - 1));
     else if (Ldyn > 0) out = res_pack(RES_DYN, (uint32_t)Ld, (uint32_t)(i + (int)D.n - pd - 1));  // backref.go:66, masked to 21 bits
     res[sg.off + i] = out;
@@ -740,8 +612,10 @@ void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const Batc
     if (n_segs == 0 || max_n <= (uint32_t)HEAD) return;
     static const int ablate = getenv("MI355_LZSS_ABLATE") ? atoi(getenv("MI355_LZSS_ABLATE")) : 0;  // timing experiments only
     const uint32_t gx = (max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS;  // blocks per segment
+    // for_emit: the results feed the phrase walk and the emitter only (not the per-position debug view)
+    const int defer = (skip_unqueried && max_n + 1 < RES_DEFER_MAX_N) ? 1 : 0;
     hipLaunchKernelGGL(match_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(MATCH_THREADS), 0, stream, d_segs, n_segs, gx,
-                       ix, dict, d_res, skip_unqueried ? 1 : 0, ablate);
+                       ix, dict, d_res, skip_unqueried ? 1 : 0, defer, ablate);
 }
 
 }  // namespace lzss

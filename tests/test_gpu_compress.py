@@ -96,6 +96,36 @@ def test_overlapped_sub_batches_give_the_same_bytes(amd, dict_naive):
             assert got == want, f"parts={parts}"
 
 
+def _maxsize():
+    import importlib.util
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_maxsize", os.path.join(here, "make_maxsize.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(here, "maxsize.json")) as f:
+        return mod.cases(), json.load(f)
+
+
+def test_inputs_beyond_two_mib_match_the_oracle_digests(amd):
+    """MaxInputSize (compress.go:473) and texts longer than the 21-bit window (backref.go:27-37), where the long
+    window slides: the oracle takes minutes there, so its outputs are committed as digests
+    (tests/golden/make_maxsize.py); the GPU streams must hash to them and decode back to the inputs"""
+    import hashlib
+    cases, want = _maxsize()
+    for name, (d, x) in cases.items():
+        assert hashlib.sha256(x).hexdigest() == want[name]["in_sha256"], name
+        c = amd.Compressor(d)
+        out = c.Compress(x)
+        assert len(out) == want[name]["out_len"], name
+        assert hashlib.sha256(out).hexdigest() == want[name]["out_sha256"], name
+        # past 2^21 - len(dict) bytes a dictionary address no longer fits its 21 bits (backref.go:66-67): the stream
+        # then decodes to something else than the input, the same something for the reference's decoder and ours
+        back = amd.Decompress(out, d)
+        assert hashlib.sha256(back).hexdigest() == want[name]["dec_sha256"], name
+        assert (back == x) == want[name]["roundtrip"], name
+
+
 def unpack(amd_ty, amd_addr, amd_len):
     return list(zip(amd_ty.tolist(), amd_addr.tolist(), amd_len.tolist()))
 
