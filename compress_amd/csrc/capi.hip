@@ -374,7 +374,8 @@ static int run_walk_emit(mi355_lzss_batch *b, uint32_t header_bytes, uint32_t bi
         HIP_TRY(hipMemcpyAsync(&total, ww.out_off + b->n_blobs, 8, hipMemcpyDeviceToHost, sm));
         HIP_TRY(hipStreamSynchronize(sm));
         if ((rc = b->out.ensure((size_t)std::max<uint64_t>(total, 16))) != 0) return rc;
-        launch_emit(d_segs, b->n_blobs, b->text.as<uint8_t>(), b->res.as<uint32_t>(), batch_index(b), ww, header_bytes, bit_off,
+        HIP_TRY(hipMemsetAsync(b->out.p, 0, (size_t)std::max<uint64_t>(total, 16), sm));  // emit ORs the bytes tiles share
+        launch_emit(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), b->res.as<uint32_t>(), batch_index(b), ww, header_bytes, bit_off,
                     (uint32_t)ctx->dict.size(), ctx->res_idx[0], ctx->res_idx[1], b->out.as<uint8_t>(), b->out.bytes,
                     b->status.as<int32_t>(), sm);
     }

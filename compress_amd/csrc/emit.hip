@@ -11,8 +11,11 @@
 //                   tile, so (A) every tile resolves "enter at e -> leave at x" for all its entries
 //                   backwards, (B) one lane hops tile to tile, (C) every tile walks its own part of
 //                   the chain and sums phrase bits; a scan gives each tile its bit offset;
-//   emit_kernel     every tile packs its phrases into bytes; the two partial bytes at a tile's ends are
-//                   merged with the neighbours' after a barrier (no atomics).
+//   emit_kernel     one wave per tile: binary lifting over the tile's chain gives every lane its phrases, a scan
+//                   their bit offsets; the bits meet in an LDS image of the tile and leave as coalesced bytes
+//                   (the byte shared with a neighbouring tile by a word atomic OR into the zeroed output).
+#include <algorithm>
+
 #include "kernels.h"
 #include "window_search.h"
 
@@ -241,26 +244,12 @@ void launch_out_offsets(uint32_t n_segs, const WalkWork &ww, hipStream_t stream)
 }
 
 // ---- emit -------------------------------------------------------------------------------------------
-struct BitSink {
-    uint8_t *out;     // byte 0 of the blob's phrase stream
-    uint64_t pos;     // next byte index
-    uint64_t acc;     // pending bits, right aligned
-    int na;           // number of pending bits
-    bool first;       // the next flushed byte is shared with the previous tile
-    uint8_t head;
-    __device__ inline void put(uint64_t v, int nb) {
-        acc = (acc << nb) | v;
-        na += nb;
-        while (na >= 8) {
-            const uint8_t byte = (uint8_t)(acc >> (na - 8));
-            na -= 8;
-            if (first) { head = byte; first = false; }
-            else out[pos] = byte;
-            ++pos;
-        }
-        acc &= (1ull << na) - 1ull;
-    }
-};
+// One wave per visited tile.  The chain inside a tile is a pointer chase (x -> x + advance(x)); binary lifting turns
+// it into lookups: s_jump[k][x] = the position 2^k phrases after x (TILE = out of the tile), so lane l finds phrases
+// l, l + 64, l + 128, l + 192 of the tile directly, wave scans of their bit counts place them, and every phrase ORs its bits into
+// the tile's LDS image, which leaves for HBM as coalesced bytes.  The byte a tile shares with a neighbour (its
+// stream is not byte aligned) is ORed into the zeroed output with a word atomic; all others are plain stores.
+constexpr int EMIT_WORDS = 304;  // 256 one-byte dynamic references (37 bits each) behind a 7-bit lead-in, + 2 words slack
 
 // address bits of a result match_kernel left pending: the smallest-rank occurrence of the match inside the window
 // (compress.go:444: windowStart = max(0, i - maxAddress)), searched from the rank stored in the field
@@ -271,119 +260,177 @@ __device__ inline uint32_t resolve_field(const SegIndex &S, uint32_t r, int i, b
     return (uint32_t)(i - p - 1);
 }
 
-__global__ __launch_bounds__(WALK_THREADS) void emit_kernel(const Seg *segs, const uint8_t *text, const uint32_t *res,
-                                                            BatchIndex ix, WalkWork ww, uint32_t header_bytes, uint32_t bit_off,
-                                                            uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
-                                                            uint8_t *out_buf, uint64_t out_cap, int32_t *status) {
-    const Seg sg = segs[blockIdx.x];
-    const int n = (int)sg.n, start = (int)sg.start;
-    const int tid = threadIdx.x;
-    const uint64_t ooff = ww.out_off[blockIdx.x];
-    const uint32_t olen = ww.out_len[blockIdx.x];
-    if (ooff + olen > out_cap) {
-        if (tid == 0) status[blockIdx.x] = -5;  // MI355_LZSS_E_CAPACITY
-        return;
-    }
-    if (tid == 0) status[blockIdx.x] = 0;
-    const uint8_t *T = text + sg.off;
-    const uint32_t *R = res + sg.off;
-    const SegIndex S = seg_index(ix, sg);
-    const uint8_t *adv = ww.adv + sg.off;
-    const uint8_t *kind = ww.kind + sg.off;
-    const uint16_t *entry = ww.entry + sg.off / TILE;
-    const uint64_t *tilebit = ww.tilebit + sg.off / TILE;
-    uint8_t *headb = ww.headb + sg.off / TILE;
-    uint8_t *tailb = ww.tailb + sg.off / TILE;
-    uint8_t *out = out_buf + ooff;
-    if (tid == 0 && header_bytes == LZSS_HEADER_SIZE) {  // lzss/header.go:22-32, NoCompression = false
-        out[0] = (uint8_t)(LZSS_VERSION >> 8);
-        out[1] = (uint8_t)(LZSS_VERSION & 0xFF);
-        out[2] = 0;
-    }
-    out += header_bytes;
-    const int ntiles = (n + TILE - 1) / TILE;
-    const int t0 = start / TILE;
-    if (start >= n) {  // empty Write: only the (zero) partial byte, if any
-        if (tid == 0 && bit_off != 0) out[0] = 0;
-        return;
-    }
+// OR the nb (1..37) low bits of v into the MSB-first bit image w at bit offset o
+__device__ inline void image_put(uint32_t *w, uint32_t o, uint64_t v, int nb) {
+    const uint64_t x = v << (64 - nb);
+    const uint32_t sh = o & 31u, wi = o >> 5;
+    const uint64_t y = x >> sh;
+    const uint32_t w0 = (uint32_t)(y >> 32), w1 = (uint32_t)y;
+    const uint32_t w2 = sh ? (uint32_t)((x << (64 - sh)) >> 32) : 0u;
+    if (w0) atomicOr(&w[wi], w0);
+    if (w1) atomicOr(&w[wi + 1], w1);
+    if (w2) atomicOr(&w[wi + 2], w2);
+}
 
-    for (int t = t0 + tid; t < ntiles; t += WALK_THREADS) {
-        const uint32_t e = entry[t];
-        if (e == 0xFFFFu) continue;
-        const uint64_t b0 = tilebit[t];
-        BitSink s;
-        s.out = out;
-        s.pos = b0 >> 3;
-        s.acc = 0;
-        s.na = (int)(b0 & 7);
-        s.first = (b0 & 7) != 0;
-        s.head = 0;
-        const int tend = (t + 1) * TILE;
-        const int hi = tend < n ? tend : n;
-        for (int i = t * TILE + (int)e; i < hi;) {
-            const uint8_t k = kind[i];
-            const int a = (int)adv[i] + 1;
-            switch (k) {
-                case K_LIT: s.put(T[i], 8); break;
-                case K_LIT2: s.put(((uint64_t)T[i] << 8) | T[i + 1], 16); break;
-                case K_SHORT: {
-                    const uint32_t r = R[i];
-                    const uint32_t f = res_pending(r) ? resolve_field(S, r, i, true) : res_field(r);
-                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(res_len(r) - 1) << 14) | (f & 0x3FFFu), LZSS_SHORT_BITS);
-                    break;
-                }
-                case K_DYN: {
-                    const uint32_t r = R[i];
-                    const uint32_t f = res_pending(r) ? resolve_field(S, r, i, false) : res_field(r);
-                    s.put(((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | ((uint64_t)(res_len(r) - 1) << 21) | f, LZSS_DYN_BITS);
-                    break;
-                }
-                case K_RLE_CONT:  // short ref at address i-1, length count (compress.go:209-212)
-                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(a - 1) << 14), LZSS_SHORT_BITS);
-                    break;
-                case K_RLE_LIT:  // the byte itself, then a short ref of length count-1 (compress.go:201-212)
-                    s.put(T[i], 8);
-                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(a - 2) << 14), LZSS_SHORT_BITS);
-                    break;
-                default: {  // K_RLE_RES: length-1 reference to the reserved symbol in the dictionary (compress.go:192-200)
-                    const int idx = T[i] == LZSS_SYMBOL_DYNAMIC ? res_idx_ff : res_idx_fe;
-                    const uint64_t field = (uint64_t)((uint32_t)(i + (int)dict_len - idx - 1) & 0x1FFFFFu);
-                    s.put(((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | field, LZSS_DYN_BITS);
-                    s.put(((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(a - 2) << 14), LZSS_SHORT_BITS);
-                    break;
-                }
-            }
-            i += a;
+__global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, const uint8_t *text,
+                                                  const uint32_t *res, BatchIndex ix, WalkWork ww, uint32_t header_bytes,
+                                                  uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
+                                                  uint8_t *out_buf, uint64_t out_cap, int32_t *status) {
+    __shared__ uint32_t s_kind32[64], s_adv32[64], s_text32[65], s_res[TILE], s_out[EMIT_WORDS];
+    __shared__ uint16_t s_jump[7][TILE + 2];
+    const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);
+    if (vb >= gx * n_segs) return;
+    const uint32_t si = vb / gx;
+    const int t = (int)(vb % gx);
+    const Seg sg = segs[si];
+    const int n = (int)sg.n, start = (int)sg.start;
+    const int lane = threadIdx.x;
+    const uint64_t ooff = ww.out_off[si];
+    const uint32_t olen = ww.out_len[si];
+    const bool fits = ooff + olen <= out_cap;
+    uint8_t *out = out_buf + ooff;
+    if (t == 0 && lane == 0) {
+        status[si] = fits ? 0 : -5;  // MI355_LZSS_E_CAPACITY
+        if (fits && header_bytes == LZSS_HEADER_SIZE) {  // lzss/header.go:22-32, NoCompression = false
+            out[0] = (uint8_t)(LZSS_VERSION >> 8);
+            out[1] = (uint8_t)(LZSS_VERSION & 0xFF);
+            out[2] = 0;
         }
-        headb[t] = s.head;
-        tailb[t] = s.na ? (uint8_t)(s.acc << (8 - s.na)) : 0;
+    }
+    const int ntiles = (n + TILE - 1) / TILE;
+    if (!fits || start >= n || t < start / TILE || t >= ntiles) return;  // an empty Write leaves the zeroed partial byte
+    const uint32_t e = ww.entry[sg.off / TILE + t];
+    if (e == 0xFFFFu) return;
+    out += header_bytes;
+    const uint64_t b0 = ww.tilebit[sg.off / TILE + t];
+    const int tbase = t * TILE;
+    const int hi = (n - tbase) < TILE ? (n - tbase) : TILE;
+    const size_t gbase = (size_t)sg.off + (size_t)tbase;
+
+    // stage the tile (the arrays are padded to whole tiles; the byte after the tile belongs to the next tile, if any)
+    s_kind32[lane] = reinterpret_cast<const uint32_t *>(ww.kind + gbase)[lane];
+    s_adv32[lane] = reinterpret_cast<const uint32_t *>(ww.adv + gbase)[lane];
+    s_text32[lane] = reinterpret_cast<const uint32_t *>(text + gbase)[lane];
+    if (lane == 0) s_text32[64] = (t + 1 < ntiles) ? text[gbase + TILE] : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_res[lane + 64 * q] = res[gbase + lane + 64 * q];
+    for (int j = lane; j < EMIT_WORDS; j += 64) s_out[j] = 0;
+    if (lane < 7) s_jump[lane][TILE] = TILE;
+    __syncthreads();
+    const uint8_t *s_kind = (const uint8_t *)s_kind32, *s_adv = (const uint8_t *)s_adv32, *s_text = (const uint8_t *)s_text32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int x = lane + 64 * q;
+        const int nx = x + (int)s_adv[x] + 1;
+        s_jump[0][x] = (uint16_t)((x < hi && nx < hi) ? nx : TILE);
     }
     __syncthreads();
-    // merge the partial bytes at tile seams; the last visited tile writes the zero-padded final byte
-    for (int t = t0 + tid; t < ntiles; t += WALK_THREADS) {
-        if (entry[t] == 0xFFFFu) continue;
-        const uint64_t b0 = tilebit[t];
-        if (b0 & 7) {
-            uint8_t v = headb[t];
-            if (t > t0) v |= tailb[t - 1];
-            out[b0 >> 3] = v;
+    for (int k = 1; k < 7; ++k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int x = lane + 64 * q;
+            s_jump[k][x] = s_jump[k - 1][s_jump[k - 1][x]];
         }
-        const bool last = (t + 1 >= ntiles) || entry[t + 1] == 0xFFFFu;
-        if (last) {
-            const uint64_t b1 = (uint64_t)bit_off + ww.nbits[blockIdx.x];
-            if (b1 & 7) out[b1 >> 3] = tailb[t];
+        __syncthreads();
+    }
+    // my phrases: numbers lane, lane + 64, lane + 128, lane + 192 of the tile (most tiles hold fewer than 64, so the
+    // phrases - and the offset searches some of them still need - spread over the lanes)
+    int xs[4];
+    {
+        int x = (int)e;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if ((lane >> k) & 1) x = s_jump[k][x];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xs[j] = x;
+            x = s_jump[6][x];
+        }
+    }
+    const uint32_t lead = (uint32_t)(b0 & 7);
+    uint32_t nb[4], off[4], total = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        nb[j] = xs[j] < TILE ? kind_bits(s_kind[xs[j]]) : 0u;
+        uint32_t inc = nb[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        off[j] = lead + total + inc - nb[j];
+        total += __shfl(inc, 63);
+    }
+    const SegIndex S = seg_index(ix, sg);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = xs[j];
+        if (x >= TILE) continue;
+        const int i = tbase + x;
+        const uint8_t k = s_kind[x];
+        const uint32_t a = (uint32_t)s_adv[x] + 1u;
+        uint64_t v1, v2 = 0;
+        int n1, n2 = 0;
+        switch (k) {
+            case K_LIT: v1 = s_text[x]; n1 = 8; break;
+            case K_LIT2: v1 = ((uint64_t)s_text[x] << 8) | s_text[x + 1]; n1 = 16; break;
+            case K_SHORT: {
+                const uint32_t r = s_res[x];
+                const uint32_t f = res_pending(r) ? resolve_field(S, r, i, true) : res_field(r);
+                v1 = ((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(res_len(r) - 1) << 14) | (f & 0x3FFFu);
+                n1 = LZSS_SHORT_BITS;
+                break;
+            }
+            case K_DYN: {
+                const uint32_t r = s_res[x];
+                const uint32_t f = res_pending(r) ? resolve_field(S, r, i, false) : res_field(r);
+                v1 = ((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | ((uint64_t)(res_len(r) - 1) << 21) | f;
+                n1 = LZSS_DYN_BITS;
+                break;
+            }
+            case K_RLE_CONT:  // short ref at address i-1, length count (compress.go:209-212)
+                v1 = ((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(a - 1) << 14);
+                n1 = LZSS_SHORT_BITS;
+                break;
+            case K_RLE_LIT:  // the byte itself, then a short ref of length count-1 (compress.go:201-212)
+                v1 = s_text[x]; n1 = 8;
+                v2 = ((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(a - 2) << 14); n2 = LZSS_SHORT_BITS;
+                break;
+            default: {  // K_RLE_RES: length-1 reference to the reserved symbol in the dictionary (compress.go:192-200)
+                const int idx = s_text[x] == LZSS_SYMBOL_DYNAMIC ? res_idx_ff : res_idx_fe;
+                v1 = ((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | (uint64_t)((uint32_t)(i + (int)dict_len - idx - 1) & 0x1FFFFFu);
+                n1 = LZSS_DYN_BITS;
+                v2 = ((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(a - 2) << 14); n2 = LZSS_SHORT_BITS;
+                break;
+            }
+        }
+        image_put(s_out, off[j], v1, n1);
+        if (n2) image_put(s_out, off[j] + (uint32_t)n1, v2, n2);
+    }
+    __syncthreads();
+    const uint32_t nbytes = (lead + total + 7) >> 3, tailbits = (lead + total) & 7u;
+    uint8_t *dst = out + (b0 >> 3);
+    for (uint32_t j = lane; j < nbytes; j += 64) {
+        const uint32_t byte = (s_out[j >> 2] >> (24 - 8 * (j & 3))) & 0xFFu;
+        const bool shared = (j == 0 && lead) || (j + 1 == nbytes && tailbits);
+        uint8_t *pb = dst + j;
+        if (!shared) {
+            *pb = (uint8_t)byte;
+        } else if (byte) {
+            const uintptr_t ad = (uintptr_t)pb;
+            atomicOr(reinterpret_cast<uint32_t *>(ad & ~(uintptr_t)3), byte << (8 * (ad & 3)));
         }
     }
 }
 
-void launch_emit(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const uint32_t *d_res, const BatchIndex &ix,
+void launch_emit(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint32_t *d_res, const BatchIndex &ix,
                  const WalkWork &ww,
                  uint32_t header_bytes, uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                  uint8_t *d_out, uint64_t out_cap, int32_t *d_status, hipStream_t stream) {
     if (n_segs == 0) return;
-    hipLaunchKernelGGL(emit_kernel, dim3(n_segs), dim3(WALK_THREADS), 0, stream, d_segs, d_text, d_res, ix, ww, header_bytes,
-                       bit_off, dict_len, res_idx_fe, res_idx_ff, d_out, out_cap, d_status);
+    const uint32_t gx = std::max<uint32_t>(1u, (max_n + TILE - 1) / TILE);  // tiles per segment; tile 0 also reports the status
+    hipLaunchKernelGGL(emit_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(64), 0, stream, d_segs, n_segs, gx, d_text, d_res,
+                       ix, ww, header_bytes, bit_off, dict_len, res_idx_fe, res_idx_ff, d_out, out_cap, d_status);
 }
 
 }  // namespace lzss

@@ -84,7 +84,7 @@ void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uin
 void launch_walk(const Seg *d_segs, uint32_t n_segs, const WalkWork &ww, uint32_t header_bytes, uint32_t bit_off,
                  hipStream_t stream);
 void launch_out_offsets(uint32_t n_segs, const WalkWork &ww, hipStream_t stream);
-void launch_emit(const Seg *d_segs, uint32_t n_segs, const uint8_t *d_text, const uint32_t *d_res, const BatchIndex &ix,
+void launch_emit(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint32_t *d_res, const BatchIndex &ix,
                  const WalkWork &ww,
                  uint32_t header_bytes, uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                  uint8_t *d_out, uint64_t out_cap, int32_t *d_status, hipStream_t stream);

@@ -613,7 +613,8 @@ void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const Batc
     static const int ablate = getenv("MI355_LZSS_ABLATE") ? atoi(getenv("MI355_LZSS_ABLATE")) : 0;  // timing experiments only
     const uint32_t gx = (max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS;  // blocks per segment
     // for_emit: the results feed the phrase walk and the emitter only (not the per-position debug view)
-    const int defer = (skip_unqueried && max_n + 1 < RES_DEFER_MAX_N) ? 1 : 0;
+    static const bool no_defer = getenv("MI355_LZSS_NO_DEFER") != nullptr;  // timing experiments only
+    const int defer = (skip_unqueried && !no_defer && max_n + 1 < RES_DEFER_MAX_N) ? 1 : 0;
     hipLaunchKernelGGL(match_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(MATCH_THREADS), 0, stream, d_segs, n_segs, gx,
                        ix, dict, d_res, skip_unqueried ? 1 : 0, defer, ablate);
 }
