@@ -106,7 +106,8 @@ struct mi355_lzss_batch {
     DevBuf text, sortA, sortB, rkA, rkB, flags, rlen, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
     DevBuf pmin1, pmax1, pmin2, pmax2, samin1, samin2;  // per 64 entries
     DevBuf cdir;                                        // per 64 ranks and chunk
-    DevBuf entry, tilebit, headb, tailb;  // per 256-tile
+    DevBuf tbits;                   // per position
+    DevBuf entry, tilebit;          // per 256-tile
     DevBuf segs, nbits, out_off, out_len, status;  // per blob
     DevBuf out;                                    // compressed bytes, blob b at out_off[b]
     PinBuf h_stage;                                // pinned staging for uploads / downloads
@@ -140,7 +141,7 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
         const uint64_t e = elems;
 #define R(buf, bytes_per) if ((rc = b->buf.ensure((size_t)(e * (bytes_per)))) != 0) return rc;
         R(text, 1) R(sortA, 8) R(sortB, 8) R(rlen, 1)  // rkA, rkB, flags: only with the fallback suffix sort (upload)
-        R(sa, 4) R(isa, 4) R(lcp, 2) R(res, 4) R(adv, 1) R(kind, 1) R(exitoff, 1)
+        R(sa, 4) R(isa, 4) R(lcp, 2) R(res, 4) R(adv, 1) R(kind, 1) R(exitoff, 1) R(tbits, 2)
 #undef R
         const uint64_t e64 = e / 64 + 1, e256 = e / 256 + 1;
         if ((rc = b->b1.ensure(e64 * 2)) != 0) return rc;
@@ -149,8 +150,6 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
             if ((rc = d->ensure(e64 * 4)) != 0) return rc;
         if ((rc = b->entry.ensure(e256 * 2)) != 0) return rc;
         if ((rc = b->tilebit.ensure(e256 * 8)) != 0) return rc;
-        if ((rc = b->headb.ensure(e256)) != 0) return rc;
-        if ((rc = b->tailb.ensure(e256)) != 0) return rc;
         b->cap_elems = elems;
     }
     if (max_blobs > b->max_blobs) {
@@ -194,7 +193,7 @@ static WalkWork walk_work(mi355_lzss_batch *b) {
     WalkWork w;
     w.adv = b->adv.as<uint8_t>(); w.kind = b->kind.as<uint8_t>(); w.exitoff = b->exitoff.as<uint8_t>();
     w.entry = b->entry.as<uint16_t>(); w.tilebit = b->tilebit.as<uint64_t>();
-    w.headb = b->headb.as<uint8_t>(); w.tailb = b->tailb.as<uint8_t>();
+    w.tbits = b->tbits.as<uint16_t>();
     w.nbits = b->nbits.as<uint64_t>(); w.out_off = b->out_off.as<uint64_t>(); w.out_len = b->out_len.as<uint32_t>();
     return w;
 }
@@ -230,7 +229,7 @@ extern "C" void mi355_lzss_batch_destroy(mi355_lzss_batch *b) {
     (void)hipSetDevice(b->ctx->device);
     DevBuf *bufs[] = {&b->text, &b->sortA, &b->sortB, &b->rkA, &b->rkB, &b->flags, &b->rlen, &b->sa, &b->isa,
                       &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->cdir, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
-                      &b->headb, &b->tailb, &b->segs, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->out,
+                      &b->tbits, &b->segs, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->out,
                       &b->d_cin, &b->d_cin_off, &b->d_dout, &b->d_dout_off, &b->d_dlen, &b->d_dstatus};
     for (DevBuf *d : bufs) d->release();
     b->h_stage.release();

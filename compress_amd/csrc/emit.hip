@@ -6,11 +6,11 @@
 // The loop `for i := start; i < n; i += advance(i)` is a chain, but advance(i) and the phrase chosen
 // at i are pure functions of the position (the RLE test compress.go:180-184, bestBackref at i, i+1,
 // i+2).  So:
-//   decide_kernel   every position in parallel: phrase kind + advance (<= 256);
-//   walk_kernel     one workgroup per blob; because advance <= 256 the chain never skips a 256-position
-//                   tile, so (A) every tile resolves "enter at e -> leave at x" for all its entries
-//                   backwards, (B) one lane hops tile to tile, (C) every tile walks its own part of
-//                   the chain and sums phrase bits; a scan gives each tile its bit offset;
+//   decide_kernel   every position in parallel: phrase kind + advance (<= 256); then, per 256-position tile and
+//                   by pointer doubling, "enter at x -> land e positions into the next tile, having written b
+//                   bits" for every x (because advance <= 256 the chain never skips a tile);
+//   walk_kernel     one workgroup per blob: one lane hops tile to tile through those tables, a scan of the
+//                   visited tiles' bits gives each tile its bit offset;
 //   emit_kernel     one wave per tile: binary lifting over the tile's chain gives every lane its phrases, a scan
 //                   their bit offsets; the bits meet in an LDS image of the tile and leave as coalesced bytes
 //                   (the byte shared with a neighbouring tile by a word atomic OR into the zeroed output).
@@ -31,82 +31,122 @@ __device__ inline int savings_of(uint32_t r) {  // backref.savings, lzss/backref
     return 8 * (int)res_len(r) - (t == RES_SHORT ? LZSS_SHORT_BITS : LZSS_DYN_BITS);
 }
 
+// One workgroup per 256-position tile.  After the phrase at every position is known, the tile also resolves, for
+// every position x, where the chain x -> x + advance(x) first lands past the tile and how many phrase bits it writes
+// on the way (pointer doubling in LDS: <= 8 rounds, fewer when every chain has left the tile) - what walk_kernel
+// needs to hop from tile to tile without ever walking inside one.
 __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs, const uint8_t *text, const uint8_t *rlen,
-                                                                const uint32_t *res, uint8_t *adv_out, uint8_t *kind_out) {
+                                                                const uint32_t *res, uint8_t *adv_out, uint8_t *kind_out,
+                                                                uint8_t *exit_out, uint16_t *bits_out) {
+    static_assert(DECIDE_THREADS == TILE, "one thread per position of a tile");
+    __shared__ uint16_t s_j[2][TILE], s_b[2][TILE];
     const Seg sg = segs[blockIdx.y];
     const int n = (int)sg.n;
-    const int i = (int)(blockIdx.x * DECIDE_THREADS + threadIdx.x);
-    if (i >= n || i < (int)sg.start) return;
+    const int tbase = (int)(blockIdx.x * TILE), tend = tbase + TILE;
+    if (tbase >= n || tend <= (int)sg.start) return;
+    const int x = (int)threadIdx.x;
+    const int i = tbase + x;
+    const bool valid = i < n && i >= (int)sg.start;
     const uint8_t *T = text + sg.off;
     const uint32_t *R = res + sg.off;
-    const uint8_t c = T[i];
-    const bool reserved = c >= LZSS_SYMBOL_SHORT;
-
-    // run of equal bytes starting at i, capped at 256 and at the end of the buffer (compress.go:180-183)
-    const int lim = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
-    int count = rlen[sg.off + i];  // the suffix sort's run lengths, capped at 255
-    if (count == 255 && lim > 255 && T[i + 255] == c) count = 256;
-    if (count > lim) count = lim;
-    int advance;
-    uint8_t kind;
-    if (count >= LZSS_MIN_REPEAT) {  // compress.go:184-218
-        advance = count;
-        if (i > 0 && T[i - 1] == c) kind = K_RLE_CONT;
-        else kind = reserved ? K_RLE_RES : K_RLE_LIT;
-    } else {
-        const uint32_t r0 = R[i];
-        const int s0 = savings_of(r0);
-        const uint8_t refkind = res_type(r0) == RES_SHORT ? K_SHORT : K_DYN;
-        if (reserved) {  // compress.go:221-226 (a dictionary reference of length 1 always exists)
-            kind = refkind;
-            advance = (int)res_len(r0);
-            if (res_type(r0) == RES_NONE) { kind = K_LIT; advance = 1; }  // unreachable; keeps the chain finite
-        } else if (s0 < 0) {  // compress.go:227-232
-            kind = K_LIT;
-            advance = 1;
-        } else if (i + 1 < n && savings_of(R[i + 1]) > s0 + 1) {  // compress.go:235-242
-            kind = K_LIT;
-            advance = 1;
-        } else if (i + 2 < n && T[i + 1] < LZSS_SYMBOL_SHORT && savings_of(R[i + 2]) > s0 + 2) {  // :243-253
-            kind = K_LIT2;
-            advance = 2;
-        } else {  // compress.go:255-256
-            kind = refkind;
-            advance = (int)res_len(r0);
+    int advance = 1;
+    uint8_t kind = K_LIT;
+    if (valid) {
+        const uint8_t c = T[i];
+        const bool reserved = c >= LZSS_SYMBOL_SHORT;
+        // run of equal bytes starting at i, capped at 256 and at the end of the buffer (compress.go:180-183)
+        const int lim = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
+        int count = rlen[sg.off + i];  // the suffix sort's run lengths, capped at 255
+        if (count == 255 && lim > 255 && T[i + 255] == c) count = 256;
+        if (count > lim) count = lim;
+        if (count >= LZSS_MIN_REPEAT) {  // compress.go:184-218
+            advance = count;
+            if (i > 0 && T[i - 1] == c) kind = K_RLE_CONT;
+            else kind = reserved ? K_RLE_RES : K_RLE_LIT;
+        } else {
+            const uint32_t r0 = R[i];
+            const int s0 = savings_of(r0);
+            const uint8_t refkind = res_type(r0) == RES_SHORT ? K_SHORT : K_DYN;
+            if (reserved) {  // compress.go:221-226 (a dictionary reference of length 1 always exists)
+                kind = refkind;
+                advance = (int)res_len(r0);
+                if (res_type(r0) == RES_NONE) { kind = K_LIT; advance = 1; }  // unreachable; keeps the chain finite
+            } else if (s0 < 0) {  // compress.go:227-232
+                kind = K_LIT;
+                advance = 1;
+            } else if (i + 1 < n && savings_of(R[i + 1]) > s0 + 1) {  // compress.go:235-242
+                kind = K_LIT;
+                advance = 1;
+            } else if (i + 2 < n && T[i + 1] < LZSS_SYMBOL_SHORT && savings_of(R[i + 2]) > s0 + 2) {  // :243-253
+                kind = K_LIT2;
+                advance = 2;
+            } else {  // compress.go:255-256
+                kind = refkind;
+                advance = (int)res_len(r0);
+            }
         }
+        adv_out[sg.off + i] = (uint8_t)(advance - 1);
+        kind_out[sg.off + i] = kind;
     }
-    adv_out[sg.off + i] = (uint8_t)(advance - 1);
-    kind_out[sg.off + i] = kind;
+    // chain state: < TILE = position inside the tile; TILE + e = left the tile, landing e positions into the next one
+    // (e = 0 also stands for "past the end of the text": the hop loop of walk_kernel stops there on its own)
+    uint32_t p = TILE, bits = 0;
+    if (valid) {
+        const int nx = i + advance;
+        p = nx >= tend ? (uint32_t)(TILE + nx - tend) : (nx >= n ? (uint32_t)TILE : (uint32_t)(nx - tbase));
+        bits = kind_bits(kind);
+    }
+    int cur = 0;
+    s_j[0][x] = (uint16_t)p;
+    s_b[0][x] = (uint16_t)bits;
+    __syncthreads();
+    for (int k = 0; k < 8; ++k) {
+        if (p < (uint32_t)TILE) {
+            bits += s_b[cur][p];
+            p = s_j[cur][p];
+        }
+        s_j[cur ^ 1][x] = (uint16_t)p;
+        s_b[cur ^ 1][x] = (uint16_t)bits;
+        cur ^= 1;
+        if (__syncthreads_count(p < (uint32_t)TILE) == 0) break;
+    }
+    if (valid) {
+        exit_out[sg.off + i] = (uint8_t)(p - TILE);
+        bits_out[sg.off + i] = (uint16_t)bits;
+    }
 }
 
 void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint8_t *d_rlen,
                    const uint32_t *d_res, const WalkWork &ww, hipStream_t stream) {
     if (n_segs == 0 || max_n == 0) return;
     dim3 g((max_n + DECIDE_THREADS - 1) / DECIDE_THREADS, n_segs);
-    hipLaunchKernelGGL(decide_kernel, g, dim3(DECIDE_THREADS), 0, stream, d_segs, d_text, d_rlen, d_res, ww.adv, ww.kind);
+    hipLaunchKernelGGL(decide_kernel, g, dim3(DECIDE_THREADS), 0, stream, d_segs, d_text, d_rlen, d_res, ww.adv, ww.kind,
+                       ww.exitoff, ww.tbits);
 }
 
 // ---- walk: visited tiles, per-tile bit offsets, per-blob size -------------------------------------
-// Groups of WG_TILES tiles are staged in LDS with coalesced 16-byte loads (adv, kind) so that the
-// per-tile sequential passes below never touch HBM byte by byte.  Tile tl's byte x lives at dword
-// ((x / 4 + tl) mod 64) of its 256-byte row: lanes (= tiles) that work on the same x hit 64 different banks.
+// One workgroup per blob.  decide_kernel left, for every position, where its chain leaves its tile (exitoff) and the
+// phrase bits up to there (tbits).  Groups of WG_TILES tiles stage their exit rows in LDS with coalesced 16-byte
+// loads; one lane hops tile to tile through them (the only serial part, one LDS read per tile), every visited tile
+// then fetches the bits of its entry and a scan gives each tile its bit offset.  Tile tl's byte x lives at dword
+// ((x / 4 + tl) mod 64) of its 256-byte row, so consecutive hops do not meet in one bank.
 constexpr int WG_TILES = 128;
 
 __device__ inline uint32_t tile_idx(int tl, int x) { return (uint32_t)(tl * 256 + ((((x >> 2) + tl) & 63) << 2) + (x & 3)); }
 
 __global__ __launch_bounds__(WALK_THREADS) void walk_kernel(const Seg *segs, WalkWork ww, uint32_t header_bytes,
                                                             uint32_t bit_off) {
-    __shared__ uint32_t s_adv32[WG_TILES * 64], s_kind32[WG_TILES * 64], s_exit32[WG_TILES * 64];
+    __shared__ uint32_t s_exit32[WG_TILES * 64];
     __shared__ uint16_t s_entry[WG_TILES];
     __shared__ uint64_t s_wave[WALK_THREADS / 64];
     __shared__ uint64_t s_carry;
     __shared__ int s_e;
-    uint8_t *s_adv = (uint8_t *)s_adv32, *s_kind = (uint8_t *)s_kind32, *s_exit = (uint8_t *)s_exit32;
+    const uint8_t *s_exit = (const uint8_t *)s_exit32;
     const Seg sg = segs[blockIdx.x];
     const int n = (int)sg.n, start = (int)sg.start;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint8_t *adv = ww.adv + sg.off;
-    const uint8_t *kind = ww.kind + sg.off;
+    const uint8_t *exitoff = ww.exitoff + sg.off;
+    const uint16_t *tbits = ww.tbits + sg.off;
     uint16_t *entry = ww.entry + sg.off / TILE;
     uint64_t *tilebit = ww.tilebit + sg.off / TILE;
     const int ntiles = (n + TILE - 1) / TILE;
@@ -118,38 +158,16 @@ __global__ __launch_bounds__(WALK_THREADS) void walk_kernel(const Seg *segs, Wal
     for (int g0 = t0; g0 < ntiles; g0 += WG_TILES) {
         const int gt = (ntiles - g0) < WG_TILES ? (ntiles - g0) : WG_TILES;
         __syncthreads();
-        // stage adv / kind of the group's tiles (the arrays are padded, reading past n is harmless)
+        // stage the exit rows of the group's tiles (the array is padded, reading past n is harmless)
         for (int c = tid; c < gt * 16; c += WALK_THREADS) {
             const int tl = c >> 4, x0 = (c & 15) * 16;
-            const size_t gpos = (size_t)(g0 + tl) * TILE + x0;
-            const uint4 va = *reinterpret_cast<const uint4 *>(adv + gpos);
-            const uint4 vk = *reinterpret_cast<const uint4 *>(kind + gpos);
-            const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, k4[4] = {vk.x, vk.y, vk.z, vk.w};
+            const uint4 ve = *reinterpret_cast<const uint4 *>(exitoff + (size_t)(g0 + tl) * TILE + x0);
+            const uint32_t e4[4] = {ve.x, ve.y, ve.z, ve.w};
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t di = (uint32_t)(tl * 64 + (((x0 >> 2) + d + tl) & 63));
-                s_adv32[di] = a4[d];
-                s_kind32[di] = k4[d];
-            }
+            for (int d = 0; d < 4; ++d) s_exit32[(uint32_t)(tl * 64 + (((x0 >> 2) + d + tl) & 63))] = e4[d];
         }
         __syncthreads();
-        // (A) for every position of my tile: where the chain from it first lands beyond the tile
-        if (tid < gt) {
-            const int tl = tid, t = g0 + tl;
-            const int tend = (t + 1) * TILE;
-            const int hi = tend < n ? tend : n;
-            const int lo = t * TILE > start ? t * TILE : start;
-            for (int i = hi - 1; i >= lo; --i) {
-                const int nx = i + (int)s_adv[tile_idx(tl, i & 255)] + 1;
-                uint8_t e;
-                if (nx >= tend) e = (uint8_t)(nx - tend);
-                else if (nx >= n) e = 0;
-                else e = s_exit[tile_idx(tl, nx & 255)];
-                s_exit[tile_idx(tl, i & 255)] = e;
-            }
-        }
-        __syncthreads();
-        // (B) hop from tile to tile
+        // hop from tile to tile
         if (tid == 0) {
             int e = s_e;
             for (int tl = 0; tl < gt; ++tl) {
@@ -164,21 +182,12 @@ __global__ __launch_bounds__(WALK_THREADS) void walk_kernel(const Seg *segs, Wal
             s_e = e;
         }
         __syncthreads();
-        // (C) bits per tile, exclusive scan in tile order
+        // bits per visited tile, exclusive scan in tile order
         uint64_t bits = 0;
         uint32_t ent = 0xFFFFu;
         if (tid < gt) {
-            const int tl = tid, t = g0 + tl;
-            ent = s_entry[tl];
-            if (ent != 0xFFFFu) {
-                const int tend = (t + 1) * TILE;
-                const int hi = tend < n ? tend : n;
-                for (int i = t * TILE + (int)ent; i < hi;) {
-                    const uint32_t ix = tile_idx(tl, i & 255);
-                    bits += kind_bits(s_kind[ix]);
-                    i += (int)s_adv[ix] + 1;
-                }
-            }
+            ent = s_entry[tid];
+            if (ent != 0xFFFFu) bits = tbits[(size_t)(g0 + tid) * TILE + ent];
         }
         uint64_t inc = bits;
 #pragma unroll

@@ -71,8 +71,7 @@ struct WalkWork {
     uint8_t *exitoff;   // [seg.off + i]  where the chain from i first lands past i's 256-tile
     uint16_t *entry;    // [seg.off/256 + t] offset of the first visited position in tile t, 0xFFFF = none
     uint64_t *tilebit;  // [seg.off/256 + t] bit offset of tile t's first phrase in the blob's stream
-    uint8_t *headb;     // [seg.off/256 + t] tile t's share of the byte it shares with tile t-1
-    uint8_t *tailb;     // [seg.off/256 + t] tile t's share of the byte it shares with tile t+1
+    uint16_t *tbits;    // [seg.off + i]  phrase bits the chain from i writes before it leaves i's tile
     uint64_t *nbits;    // [seg] phrase bits of the blob
     uint64_t *out_off;  // [seg], n_segs+1 entries: byte offset of the blob's output in the batch output buffer
     uint32_t *out_len;  // [seg] bytes written (header + ceil(bits/8))
