@@ -136,6 +136,25 @@ __device__ inline int lcp_run(const uint8_t *T, const uint8_t *RL, uint32_t a, u
     return lcp_bytes(T + a, T + b, r < lim ? r : lim, lim);
 }
 
+// lcp_run for the LCP array (neighbours in rank: the first bytes are nearly always equal): the first 8 text bytes
+// and the run lengths of both suffixes are fetched in ONE round trip; they settle the first-byte test, unequal runs
+// and every prefix shorter than 8, so only longer prefixes pay for a compare loop.  (32 bytes per compare step was
+// measured slower: this kernel is bound by the number of scattered loads, not by the length of their chain.)
+__device__ inline int lcp_run_rank(const uint8_t *T, const uint8_t *RL, uint32_t a, uint32_t b, int lim) {
+    if (lim <= 0) return 0;
+    const uint64_t x = ld8(T + a) ^ ld8(T + b);
+    const int ra = RL[a], rb = RL[b];
+    if (x & 0xFFull) return 0;
+    const int r = ra < rb ? ra : rb;
+    if (ra != rb) return r < lim ? r : lim;
+    if (x) {
+        const int l = (int)(__builtin_ctzll(x) >> 3);
+        return l < lim ? l : lim;
+    }
+    const int from = r > 8 ? r : 8;
+    return lcp_bytes(T + a, T + b, from < lim ? from : lim, lim);
+}
+
 typedef uint16_t u16x8_t __attribute__((ext_vector_type(8)));
 
 // largest index <= j inside the 8-aligned group of j whose value is < L, or -1 (one 16-byte load)

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, Batch
             const uint32_t hi = a > b ? a : b;
             int lim = (int)(sg.n - hi);  // the shorter suffix ends at the sentinel
             if (lim > LZSS_MAX_LEN) lim = LZSS_MAX_LEN;
-            l = (uint32_t)lcp_run(T, RL, a, b, lim);
+            l = (uint32_t)lcp_run_rank(T, RL, a, b, lim);
         }
         ix.lcp[sg.off + k] = (uint16_t)l;
         if (k == N - 1)  // the upward walk of match_kernel reads up to three ranks past N and must die there
