@@ -125,10 +125,11 @@ void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchI
 // different keys also give the exact common prefix length (key_lcp) - so on zero-heavy data, where a plain 8-byte
 // prefix ties on every probe and every tie costs a text compare, almost every probe is decided by one load.
 constexpr int DICT_RUN_CAP = 254;
-__device__ inline uint64_t run_key(const uint8_t *s, int A, int &rlc) {
+// run: the length of the run of s[0] at s if the caller knows it (the text's `rlen`, capped at 255; it may exceed A), else < 0
+__device__ inline uint64_t run_key(const uint8_t *s, int A, int &rlc, int run = -1) {
     const uint32_t c = s[0];
     const int lim = (A - 1) < DICT_RUN_CAP ? (A - 1) : DICT_RUN_CAP;
-    const int rl = 1 + lcp_bytes(s, s + 1, 0, lim);
+    const int rl = run < 0 ? 1 + lcp_bytes(s, s + 1, 0, lim) : (run < lim + 1 ? run : lim + 1);
     if (rl >= DICT_RUN_CAP) {
         rlc = DICT_RUN_CAP;
         return ((uint64_t)c << 49) | (255ull << 40);
@@ -138,9 +139,10 @@ __device__ inline uint64_t run_key(const uint8_t *s, int A, int &rlc) {
     bool falling = true;
     if (rl < A) {
         const int avail = A - rl;
-        tail = __builtin_bswap64(ld8(s + rl)) >> 24;
+        const uint64_t w = ld8(s + rl);
+        tail = __builtin_bswap64(w) >> 24;
         if (avail < 5) tail &= ~((1ull << (8 * (5 - avail))) - 1ull);
-        falling = s[rl] < c;
+        falling = (uint32_t)(w & 0xFFull) < c;
     }
     const uint64_t code = falling ? (uint64_t)rl : (uint64_t)(511 - rl);
     return ((uint64_t)c << 49) | (code << 40) | tail;
@@ -240,12 +242,12 @@ __device__ inline bool dict_bucket(const DictView &D, const uint8_t *pat, int &l
 // bracket [lo, hi] (0, n + 1 for the whole dictionary).  minLen: shorter results are of no use to the caller (lets an
 // empty two-byte bucket end the search).
 __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int maxLen, int minLen, int lo, int hi, int &Ld,
-                                   int &pd, int g_ablate) {
+                                   int &pd, int g_ablate, int run = -1) {
     Ld = 0;
     pd = -1;
     if (maxLen >= 2 && !dict_bucket(D, pat, lo, hi) && minLen >= 2) return;  // nothing shares two bytes with pat
     int prl;
-    const uint64_t pk = run_key(pat, maxLen, prl);
+    const uint64_t pk = run_key(pat, maxLen, prl, run);
     dict_search(D, pat, maxLen, pk, prl, lo, hi);
     const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo);
     const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi);
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     // wave - their lower bounds are monotone in rank - was measured slower: the phases serialise the probe latency
     // and a divergent probe loop costs the same issue slots however few lanes run it.)
     int Ld = 0, pd = -1;
-    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, ablate);
+    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, ablate, (int)ix.rlen[sg.off + i]);
     MP(7)
     // selection (compress.go:160-169) BEFORE the offsets: only the window whose reference is emitted needs its
     // smallest-rank occurrence, so every lane runs at most one interval search
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
     const int Ls = best, ps = bp;
     const int LL = (dynOK && best >= minD) ? best : 0, pL = bp;
     int Ld = 0, pd = -1;
-    if (dynOK && LL < maxLen) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, 0);  // compress.go:460
+    if (dynOK && LL < maxLen) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, 0, (int)RL[i]);  // compress.go:460
     res[sg.off + i] = select_backref(D, i, minD, dynOK, Ls, ps, LL, pL, Ld, pd);
 }
 
