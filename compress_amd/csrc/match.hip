@@ -240,9 +240,10 @@ __device__ inline bool dict_bucket(const DictView &D, const uint8_t *pat, int &l
 
 // Longest prefix of pat[0:maxLen) occurring in the dictionary, and its smallest-rank occurrence, searched inside the
 // bracket [lo, hi] (0, n + 1 for the whole dictionary).  minLen: shorter results are of no use to the caller (lets an
-// empty two-byte bucket end the search).
+// empty two-byte bucket end the search).  run: the text's run length at pat, if known.  beat: the occurrence is only
+// looked up when the match is longer than this (Ld is valid either way).
 __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int maxLen, int minLen, int lo, int hi, int &Ld,
-                                   int &pd, int g_ablate, int run = -1) {
+                                   int &pd, int g_ablate, int run = -1, int beat = 0) {
     Ld = 0;
     pd = -1;
     if (maxLen >= 2 && !dict_bucket(D, pat, lo, hi) && minLen >= 2) return;  // nothing shares two bytes with pat
@@ -252,7 +253,7 @@ __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int ma
     const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo);
     const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi);
     Ld = llo > lhi ? llo : lhi;
-    if (Ld <= 0) return;
+    if (Ld <= beat) return;  // the caller only takes a strictly longer match (compress.go:464): no occurrence needed
     if (lhi > llo) {
         pd = D.SA[hi];  // nothing below hi shares Ld bytes
     } else {
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     // wave - their lower bounds are monotone in rank - was measured slower: the phases serialise the probe latency
     // and a divergent probe loop costs the same issue slots however few lanes run it.)
     int Ld = 0, pd = -1;
-    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, ablate, (int)ix.rlen[sg.off + i]);
+    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, ablate, (int)ix.rlen[sg.off + i], LL);
     MP(7)
     // selection (compress.go:160-169) BEFORE the offsets: only the window whose reference is emitted needs its
     // smallest-rank occurrence, so every lane runs at most one interval search
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
     const int Ls = best, ps = bp;
     const int LL = (dynOK && best >= minD) ? best : 0, pL = bp;
     int Ld = 0, pd = -1;
-    if (dynOK && LL < maxLen) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, 0, (int)RL[i]);  // compress.go:460
+    if (dynOK && LL < maxLen) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, 0, (int)RL[i], LL);  // compress.go:460
     res[sg.off + i] = select_backref(D, i, minD, dynOK, Ls, ps, LL, pL, Ld, pd);
 }
 
