@@ -374,7 +374,7 @@ static int run_walk_emit(mi355_lzss_batch *b, uint32_t header_bytes, uint32_t bi
         HIP_TRY(hipStreamSynchronize(sm));
         if ((rc = b->out.ensure((size_t)std::max<uint64_t>(total, 16))) != 0) return rc;
         HIP_TRY(hipMemsetAsync(b->out.p, 0, (size_t)std::max<uint64_t>(total, 16), sm));  // emit ORs the bytes tiles share
-        launch_emit(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), b->res.as<uint32_t>(), batch_index(b), ww, header_bytes, bit_off,
+        launch_emit(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), b->res.as<uint32_t>(), batch_index(b), ctx->view, ww, header_bytes, bit_off,
                     (uint32_t)ctx->dict.size(), ctx->res_idx[0], ctx->res_idx[1], b->out.as<uint8_t>(), b->out.bytes,
                     b->status.as<int32_t>(), sm);
     }
@@ -545,9 +545,9 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     CP(d_b1, b1, (stride / 64 + 1) * 2) CP(d_b2, b2, (stride / 64 + 1) * 2)
 #undef CP
     if ((rc = ctx->d_key.ensure(stride * 8)) != 0) return bail(rc);
-    if ((rc = ctx->d_bstart.ensure(65536 * 4)) != 0) return bail(rc);
-    if ((rc = ctx->d_bend.ensure(65536 * 4)) != 0) return bail(rc);
-    if (hipMemsetAsync(ctx->d_bstart.p, 0, 65536 * 4, sm) != hipSuccess || hipMemsetAsync(ctx->d_bend.p, 0, 65536 * 4, sm) != hipSuccess)
+    if ((rc = ctx->d_bstart.ensure(DICT_BUCKETS * 4)) != 0) return bail(rc);
+    if ((rc = ctx->d_bend.ensure(DICT_BUCKETS * 4)) != 0) return bail(rc);
+    if (hipMemsetAsync(ctx->d_bstart.p, 0, DICT_BUCKETS * 4, sm) != hipSuccess || hipMemsetAsync(ctx->d_bend.p, 0, DICT_BUCKETS * 4, sm) != hipSuccess)
         return bail(fail(MI355_LZSS_E_DEVICE, "hipMemsetAsync failed"));
     launch_dict_aux(ctx->d_text.as<uint8_t>(), (uint32_t)aug.size(), ctx->d_sa.as<int32_t>(), ctx->d_key.as<uint64_t>(),
                     ctx->d_bstart.as<int32_t>(), ctx->d_bend.as<int32_t>(), sm);

@@ -282,7 +282,7 @@ __device__ inline void image_put(uint32_t *w, uint32_t o, uint64_t v, int nb) {
 }
 
 __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, const uint8_t *text,
-                                                  const uint32_t *res, BatchIndex ix, WalkWork ww, uint32_t header_bytes,
+                                                  const uint32_t *res, BatchIndex ix, DictView D, WalkWork ww, uint32_t header_bytes,
                                                   uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                                                   uint8_t *out_buf, uint64_t out_cap, int32_t *status) {
     __shared__ uint32_t s_kind32[64], s_adv32[64], s_text32[65], s_res[TILE], s_out[EMIT_WORDS];
@@ -392,7 +392,14 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
             }
             case K_DYN: {
                 const uint32_t r = s_res[x];
-                const uint32_t f = res_pending(r) ? resolve_field(S, r, i, false) : res_field(r);
+                uint32_t f = res_field(r);
+                if (res_type(r) == RES_DICT) {  // backref.go:66 with the dictionary's smallest-rank occurrence
+                    const int kd = (int)f, Ld = (int)res_len(r);
+                    const int pd = D.SA[prev_lower(D.LCP, D.bmin1, D.bmin2, kd, Ld)];
+                    f = (uint32_t)(i + (int)D.n - pd - 1) & 0x1FFFFFu;
+                } else if (res_pending(r)) {
+                    f = resolve_field(S, r, i, false);
+                }
                 v1 = ((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | ((uint64_t)(res_len(r) - 1) << 21) | f;
                 n1 = LZSS_DYN_BITS;
                 break;
@@ -433,13 +440,13 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
 }
 
 void launch_emit(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint32_t *d_res, const BatchIndex &ix,
-                 const WalkWork &ww,
+                 const DictView &dict, const WalkWork &ww,
                  uint32_t header_bytes, uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                  uint8_t *d_out, uint64_t out_cap, int32_t *d_status, hipStream_t stream) {
     if (n_segs == 0) return;
     const uint32_t gx = std::max<uint32_t>(1u, (max_n + TILE - 1) / TILE);  // tiles per segment; tile 0 also reports the status
     hipLaunchKernelGGL(emit_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(64), 0, stream, d_segs, n_segs, gx, d_text, d_res,
-                       ix, ww, header_bytes, bit_off, dict_len, res_idx_fe, res_idx_ff, d_out, out_cap, d_status);
+                       ix, dict, ww, header_bytes, bit_off, dict_len, res_idx_fe, res_idx_ff, d_out, out_cap, d_status);
 }
 
 }  // namespace lzss

@@ -29,7 +29,10 @@ struct DictView {     // the dictionary index of a ctx (device pointers)
     const int32_t *bstart;     // [first two bytes] rank range [bstart, bend) of the suffixes starting with them
     const int32_t *bend;
 };
-// fills key / bstart / bend (bstart, bend must be zeroed) from the dictionary's text and suffix array
+// rank range tables of the dictionary: [0, 65536) by the first two bytes, then 2^17 entries by the top 17 bits of the
+// run-aware key (first byte, run code)
+constexpr uint32_t DICT_PAIR_BUCKETS = 65536, DICT_BUCKETS = 65536 + (1u << 17);
+// fills key / bstart / bend (DICT_BUCKETS entries each, must be zeroed) from the dictionary's text and suffix array
 void launch_dict_aux(const uint8_t *d_text, uint32_t n, const int32_t *d_sa, uint64_t *d_key, int32_t *d_bstart,
                      int32_t *d_bend, hipStream_t stream);
 struct BatchIndex {   // batch-wide index arrays
@@ -84,7 +87,7 @@ void launch_walk(const Seg *d_segs, uint32_t n_segs, const WalkWork &ww, uint32_
                  hipStream_t stream);
 void launch_out_offsets(uint32_t n_segs, const WalkWork &ww, hipStream_t stream);
 void launch_emit(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint32_t *d_res, const BatchIndex &ix,
-                 const WalkWork &ww,
+                 const DictView &dict, const WalkWork &ww,
                  uint32_t header_bytes, uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                  uint8_t *d_out, uint64_t out_cap, int32_t *d_status, hipStream_t stream);
 

@@ -33,6 +33,7 @@ constexpr int HEAD = LZSS_HEAD;         // positions below HEAD are matched by b
 constexpr uint32_t RES_NONE = 0u;
 constexpr uint32_t RES_SHORT = 1u;
 constexpr uint32_t RES_DYN = 2u;
+constexpr uint32_t RES_DICT = 3u;  // a dynamic reference into the dictionary whose address bits are pending: field = a dictionary rank
 // type:2 | pending:1 | length-1:8 | field:21.  field = the address bits as written (backref.go:66), or, while the
 // result is PENDING, the rank the search for the smallest-rank occurrence starts from (window_search.h): emit_kernel
 // finishes pending results for the phrases it writes.  Ranks need 21 bits, so only texts below 2 MiB are deferred.

@@ -32,14 +32,23 @@ namespace lzss { __device__ unsigned long long g_mp[16]; }
 #define MP_PRINT if (threadIdx.x == 0 && (blockIdx.x & 31) == 0) { for (int q_ = 0; q_ < 15; ++q_) atomicAdd(&g_mp[q_], (unsigned long long)mp_acc[q_]); atomicAdd(&g_mp[15], 1ull); }
 #define MP_ARG , long long *mp_acc, long long &mp_last
 #define MP_PASS , mp_acc, mp_last
+#define MP_NONE , mp_none_acc, mp_none_last
 #else
 #define MP_DECL
 #define MP(i)
 #define MP_PRINT
 #define MP_ARG
 #define MP_PASS
+#define MP_NONE
 #endif
 #include "window_search.h"
+
+#ifdef DICT_STATS  // event counts of the dictionary lookups of every 64th block (debug builds only)
+namespace lzss { __device__ unsigned long long g_ds[16]; }
+#define DS(k, v) { if ((blockIdx.x & 63) == 0) atomicAdd(&lzss::g_ds[k], (unsigned long long)(v)); }
+#else
+#define DS(k, v)
+#endif
 
 namespace lzss {
 
@@ -166,8 +175,24 @@ __global__ __launch_bounds__(256) void dict_aux_kernel(const uint8_t *T, uint32_
     if (k > n) return;
     const uint32_t q = (uint32_t)SA[k];
     int rlc;
-    key[k] = k == 0 ? 0ull : run_key(T + q, (int)(n - q), rlc);  // the text is zero padded past n
-    if (k == 0 || q + 2 > n) return;
+    const uint64_t kk = k == 0 ? 0ull : run_key(T + q, (int)(n - q), rlc);  // the text is zero padded past n
+    key[k] = kk;
+    if (k == 0) return;
+    {   // rank range of every (first byte, run code) = the top 17 key bits, behind the two-byte table
+        const uint32_t kt = (uint32_t)(kk >> 40);
+        bool first = k == 1, last = k == n;
+        if (!first) {
+            const uint32_t qp = (uint32_t)SA[k - 1];
+            first = (uint32_t)(run_key(T + qp, (int)(n - qp), rlc) >> 40) != kt;
+        }
+        if (!last) {
+            const uint32_t qn = (uint32_t)SA[k + 1];
+            last = (uint32_t)(run_key(T + qn, (int)(n - qn), rlc) >> 40) != kt;
+        }
+        if (first) bstart[DICT_PAIR_BUCKETS + kt] = (int32_t)k;
+        if (last) bend[DICT_PAIR_BUCKETS + kt] = (int32_t)k + 1;
+    }
+    if (q + 2 > n) return;
     const uint32_t b = ((uint32_t)T[q] << 8) | T[q + 1];
     const uint32_t qp = (uint32_t)SA[k - 1];
     const bool first = (k == 1) || qp + 2 > n || ((((uint32_t)T[qp] << 8) | T[qp + 1]) != b);
@@ -198,7 +223,9 @@ __device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen
         const int l = key_lcp(pk, kq);
         return l < lim ? l : lim;
     }
-    return lcp_bytes(pat, D.T + q, prl < lim ? prl : lim, lim);
+    const int l_ = lcp_bytes(pat, D.T + q, prl < lim ? prl : lim, lim);
+    DS(5, 1) DS(6, (l_ - (prl < lim ? prl : lim)) / 8 + 1)
+    return l_;
 }
 
 // Binary search of pat[0:maxLen) among the dictionary suffixes.  Invariant: suffix(lo) < pat <= suffix(hi); rank 0 is
@@ -211,6 +238,7 @@ __device__ inline void dict_search(const DictView &D, const uint8_t *pat, int ma
         const uint64_t kq = D.key[mid];
         bool suffix_less;
         int o = 0;
+        DS(2, 1)
         if (kq != pk) {
             suffix_less = kq < pk;  // the key order is the string order
         } else {
@@ -219,7 +247,9 @@ __device__ inline void dict_search(const DictView &D, const uint8_t *pat, int ma
             const int lim = maxLen < avail ? maxLen : avail;
             o = llo < lhi ? llo : lhi;
             const int o1 = prl < lim ? prl : lim;
+            DS(3, 1) DS(4, -(o > o1 ? o : o1))
             o = lcp_bytes(pat, D.T + q, o > o1 ? o : o1, lim);
+            DS(4, o + 8)
             if (o == maxLen) suffix_less = false;          // pat is a prefix of the suffix
             else if (o == avail) suffix_less = true;       // the suffix is a proper prefix of pat
             else suffix_less = D.T[q + o] < pat[o];
@@ -238,28 +268,42 @@ __device__ inline bool dict_bucket(const DictView &D, const uint8_t *pat, int &l
     return true;
 }
 
-// Longest prefix of pat[0:maxLen) occurring in the dictionary, and its smallest-rank occurrence, searched inside the
+// Longest prefix of pat[0:maxLen) occurring in the dictionary (Ld) and a rank kd that attains it, searched inside the
 // bracket [lo, hi] (0, n + 1 for the whole dictionary).  minLen: shorter results are of no use to the caller (lets an
-// empty two-byte bucket end the search).  run: the text's run length at pat, if known.  beat: the occurrence is only
-// looked up when the match is longer than this (Ld is valid either way).
+// empty two-byte bucket end the search).  run: the text's run length at pat, if known.  The occurrence itself
+// (dict_occurrence) is only needed for a reference that is written.
 __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int maxLen, int minLen, int lo, int hi, int &Ld,
-                                   int &pd, int g_ablate, int run = -1, int beat = 0) {
+                                   int &kd, int run MP_ARG) {
     Ld = 0;
-    pd = -1;
-    if (maxLen >= 2 && !dict_bucket(D, pat, lo, hi) && minLen >= 2) return;  // nothing shares two bytes with pat
+    kd = 0;
+    DS(0, 1)
+    if (maxLen >= 2 && !dict_bucket(D, pat, lo, hi) && minLen >= 2) { DS(1, 1) return; }  // nothing shares two bytes with pat
+    DS(8, hi - lo)
     int prl;
     const uint64_t pk = run_key(pat, maxLen, prl, run);
+    if (prl >= 2) {  // inside a run the two-byte bucket is huge (zero-heavy data): narrow to the suffixes with the same run code
+        const uint32_t kt = (uint32_t)(pk >> 40);
+        const int s = D.bstart[DICT_PAIR_BUCKETS + kt], e = D.bend[DICT_PAIR_BUCKETS + kt];
+        if (s < e) {  // the key order is the suffix order: the pattern's lower bound lies in [s, e]
+            lo = lo > s - 1 ? lo : s - 1;
+            hi = hi < e ? hi : e;
+        }
+    }
+    DS(10, hi - lo)
+    MP(12)
     dict_search(D, pat, maxLen, pk, prl, lo, hi);
+    MP(13)
     const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo);
     const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi);
     Ld = llo > lhi ? llo : lhi;
-    if (Ld <= beat) return;  // the caller only takes a strictly longer match (compress.go:464): no occurrence needed
-    if (lhi > llo) {
-        pd = D.SA[hi];  // nothing below hi shares Ld bytes
-    } else {
-        const int lo2 = (g_ablate & 8) ? lo : prev_lower(D.LCP, D.bmin1, D.bmin2, lo, Ld);
-        pd = D.SA[lo2];
-    }
+    MP(14)
+    DS(9, Ld)
+    // the smallest-rank occurrence is the first rank of the interval of suffixes sharing Ld bytes with rank kd
+    // (dict_occurrence); when hi alone attains Ld that is hi itself (LCP[hi] = lcp with lo < Ld)
+    kd = lhi > llo ? hi : lo;
+}
+__device__ inline int dict_occurrence(const DictView &D, int kd, int Ld) {
+    return D.SA[prev_lower(D.LCP, D.bmin1, D.bmin2, kd, Ld)];
 }
 
 // Apply the selection rule of compress.go:160-169 to the data-window results (Ls/ps: short window, LL/pL: long
@@ -538,8 +582,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     // dictionary (compress.go:460-466): every lane searches on its own.  (Sharing the search between the lanes of a
     // wave - their lower bounds are monotone in rank - was measured slower: the phases serialise the probe latency
     // and a divergent probe loop costs the same issue slots however few lanes run it.)
-    int Ld = 0, pd = -1;
-    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, ablate, (int)ix.rlen[sg.off + i], LL);
+    int Ld = 0, kd = 0;
+    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, kd, (int)ix.rlen[sg.off + i] MP_PASS);
     MP(7)
     // selection (compress.go:160-169) BEFORE the offsets: only the window whose reference is emitted needs its
     // smallest-rank occurrence, so every lane runs at most one interval search
@@ -566,7 +610,10 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     if (pending) out = res_pack(short_wins ? RES_SHORT : RES_DYN, (uint32_t)(short_wins ? Ls : LL), (uint32_t)p) | RES_PENDING;
     else if (short_wins) out = res_pack(RES_SHORT, (uint32_t)Ls, (uint32_t)(i - p - 1));
     else if (long_wins) out = res_pack(RES_DYN, (uint32_t)LL, (uint32_t)(i - p - 1));
-    else if (Ldyn > 0) out = res_pack(RES_DYN, (uint32_t)Ld, (uint32_t)(i + (int)D.n - pd - 1));  // backref.go:66, masked to 21 bits
+    else if (Ldyn > 0) {  // the dictionary reference: address bits i + DictLen - address - 1 masked to 21 (backref.go:66)
+        if (defer && D.n + 1 < RES_DEFER_MAX_N) out = res_pack(RES_DICT, (uint32_t)Ld, (uint32_t)kd);
+        else out = res_pack(RES_DYN, (uint32_t)Ld, (uint32_t)(i + (int)D.n - dict_occurrence(D, kd, Ld) - 1));
+    }
     res[sg.off + i] = out;
 }
 
@@ -579,6 +626,9 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
     const uint8_t *T = ix.text + sg.off;
     const uint8_t *RL = ix.rlen + sg.off;
     const int32_t *ISA = ix.isa + sg.off;
+#ifdef MATCH_PROFILE
+    long long mp_none_acc[15], mp_none_last = 0;
+#endif
 
     const int maxLen = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
     const bool reserved = T[i] >= LZSS_SYMBOL_SHORT;
@@ -597,8 +647,9 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
     }
     const int Ls = best, ps = bp;
     const int LL = (dynOK && best >= minD) ? best : 0, pL = bp;
-    int Ld = 0, pd = -1;
-    if (dynOK && LL < maxLen) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, pd, 0, (int)RL[i], LL);  // compress.go:460
+    int Ld = 0, kd = 0, pd = -1;
+    if (dynOK && LL < maxLen) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, kd, (int)RL[i] MP_NONE);  // compress.go:460
+    if (Ld >= minD && Ld > LL) pd = dict_occurrence(D, kd, Ld);
     res[sg.off + i] = select_backref(D, i, minD, dynOK, Ls, ps, LL, pL, Ld, pd);
 }
 
@@ -623,6 +674,17 @@ void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const Batc
 }
 
 }  // namespace lzss
+
+#ifdef DICT_STATS
+extern "C" int mi355_lzss_debug_dict_stats(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lzss::g_ds), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lzss::g_ds), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 #ifdef MATCH_PROFILE
 extern "C" int mi355_lzss_debug_match_profile(unsigned long long *out16, int reset) {

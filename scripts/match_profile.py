@@ -17,7 +17,7 @@ buf = (C.c_ulonglong * 16)()
 f(buf, 1)
 bt.compress()
 f(buf, 1)
-names = ["setup", "up", "coopup", "dn", "coopdn", "lengths", "leftmost_wait", "dict", "prev_lower", "linear", "short_index", "long_index", "-", "-", "-"]
+names = ["setup", "up", "coopup", "dn", "coopdn", "lengths", "leftmost_wait", "dict", "prev_lower", "linear", "short_index", "long_index", "d_bucket_key", "d_search", "d_final_lcp"]
 tot = sum(buf[:15])
 for k, nm in enumerate(names):
     print("%-8s %6.1f%%  %10.0f cycles/wave" % (nm, 100.0 * buf[k] / tot, buf[k] / max(buf[15], 1)))
