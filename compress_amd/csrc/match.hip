@@ -339,6 +339,8 @@ __device__ inline bool never_queried(const uint8_t *RL, int i) {
 #define MATCH_SCAN_CAP 8
 #endif
 constexpr int SCAN_CAP = MATCH_SCAN_CAP;  // x4 ranks a lane walks alone before its wave takes the walk over
+constexpr int WIN_HALO = 4 * SCAN_CAP + 4;                // ranks staged in LDS on each side of the wave's 64
+constexpr int WIN_TOTAL = 64 + 2 * WIN_HALO;
 
 __device__ inline uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
     const uint32_t t = a < b ? a : b;
@@ -348,11 +350,6 @@ __device__ inline uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) {
     const uint32_t t = a > b ? a : b;
     return t > c ? t : c;
 }
-
-#ifndef MATCH_COOP_THR
-#define MATCH_COOP_THR 0
-#endif
-constexpr int COOP_THR = MATCH_COOP_THR;  // lanes still walking at or below which the wave takes their walks over early
 
 __device__ inline int wave_incl_min(int v, int lane) {
 #pragma unroll
@@ -382,10 +379,27 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     const int32_t *SA = ix.sa + sg.off;
     const uint16_t *LCP = ix.lcp + sg.off;
 
+    // the wave's neighbourhood in rank, [R0 - WIN_HALO, R0 + 64 + WIN_HALO), goes to LDS once (coalesced): the
+    // lane-private part of the walks then reads LDS instead of issuing 64 overlapping 16-byte loads per step
+    static_assert(MATCH_THREADS == 64, "one wave per block: the window belongs to the wave");
+    __shared__ int32_t s_sa[WIN_TOTAL + 4];
+    __shared__ uint32_t s_lc[WIN_TOTAL + 4];
+    const int wbase = (int)(bx * MATCH_THREADS) - WIN_HALO;
+    for (int j = lane; j < WIN_TOTAL; j += 64) {
+        int g = wbase + j;
+        g = g < 0 ? 0 : (g > N + 3 ? N + 3 : g);  // LCP is zero at rank 0 and from N to N + 3: walks die there
+        s_sa[j] = SA[g];
+        s_lc[j] = LCP[g];
+    }
+    if (lane < 4) {  // what a lane that has finished reads: outside every window, an lcp that changes nothing
+        s_sa[WIN_TOTAL + lane] = 0x7FFFFFFF;
+        s_lc[WIN_TOTAL + lane] = 0xFFFFu;
+    }
+    __syncthreads();
     bool work = r >= 1 && r < N;
     int i = 0;
     if (work) {
-        i = SA[r];
+        i = s_sa[WIN_HALO + lane];
         work = !(i < (int)sg.start || i < HEAD);
     }
     if (work && skip_unqueried && never_queried(ix.rlen + sg.off, i)) {
@@ -416,21 +430,14 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     {
         int m = 1 << 20, k = r + 1;
         bool done = !scan || k >= N;
-        for (int it = 0; it < SCAN_CAP && __popcll(__ballot(!done)) > COOP_THR; ++it) {
-            I4 sa4;
-            U4 l4;
-            sa4.v = 0x7FFFFFFF;  // lanes that have finished see ranks outside every window whose lcp changes nothing
-            l4.v = 0xFFFF;
-            if (!done) {
-                sa4 = ld_i4(SA + k);
-                l4 = ld_u4(LCP + k);
-            }
+        for (int it = 0; it < SCAN_CAP && __ballot(!done); ++it) {
+            const int j = done ? WIN_TOTAL : k - wbase;
             uint32_t cS[4], cL[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int l = l4.v[t];
+                const int l = (int)s_lc[j + t];
                 m = l < m ? l : m;
-                const uint32_t d = im1 - (uint32_t)sa4.v[t];  // offset - 1; wraps to >= 2^31 for positions >= i
+                const uint32_t d = im1 - (uint32_t)s_sa[j + t];  // offset - 1; wraps to >= 2^31 for positions >= i
                 const uint32_t key = ((uint32_t)(k + t) << 9) | (uint32_t)m;
                 cS[t] = d < spanS ? key : NONE_UP;
                 cL[t] = d < spanL ? key : NONE_UP;
@@ -482,22 +489,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     {
         int m = 1 << 20, k = r - 1;
         bool done = !scan;
-        for (int it = 0; it < SCAN_CAP && __popcll(__ballot(!done && k >= 4)) > COOP_THR; ++it) {  // ranks k, k-1, k-2, k-3
+        for (int it = 0; it < SCAN_CAP && __ballot(!done && k >= 4); ++it) {  // ranks k, k-1, k-2, k-3
             const bool go = !done && k >= 4;
-            I4 sa4;
-            U4 l4;
-            sa4.v = 0x7FFFFFFF;
-            l4.v = 0xFFFF;
-            if (go) {
-                sa4 = ld_i4(SA + k - 3);
-                l4 = ld_u4(LCP + k - 2);
-            }
+            const int j = go ? k - 3 - wbase : WIN_TOTAL;  // rank kk's lcp with its upper neighbour is LCP[kk + 1]
             uint32_t cS[4], cL[4];
 #pragma unroll
             for (int t = 3; t >= 0; --t) {
-                const int l = l4.v[t];
+                const int l = (int)s_lc[go ? j + t + 1 : j + t];
                 m = l < m ? l : m;
-                const uint32_t d = im1 - (uint32_t)sa4.v[t];
+                const uint32_t d = im1 - (uint32_t)s_sa[j + t];
                 const uint32_t key = ((uint32_t)(k - 3 + t) << 9) | (uint32_t)m;
                 cS[t] = d < spanS ? key : NONE_DN;
                 cL[t] = d < spanL ? key : NONE_DN;
