@@ -59,11 +59,14 @@ constexpr int LCP_THREADS = 256;
 constexpr int MATCH_THREADS = MATCH_BLOCK;
 
 // ---- LCP array and its block minima -------------------------------------------------------------
-__global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, BatchIndex ix) {
-    const Seg sg = segs[blockIdx.y];
+__global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, BatchIndex ix) {
+    const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);  // a segment's text and run lengths meet in one XCD's L2
+    if (vb >= gx * n_segs) return;
+    const Seg sg = segs[vb / gx];
+    const uint32_t bx = vb % gx;
     const uint32_t N = sg.n + 1;
-    if (blockIdx.x * LCP_THREADS >= N) return;
-    const uint32_t k = blockIdx.x * LCP_THREADS + threadIdx.x;
+    if (bx * LCP_THREADS >= N) return;
+    const uint32_t k = bx * LCP_THREADS + threadIdx.x;
     const uint8_t *T = ix.text + sg.off;
     const uint8_t *RL = ix.rlen + sg.off;
     const int32_t *SA = ix.sa + sg.off;
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(64) void bmin2_kernel(const Seg *segs, BatchIndex i
 void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream) {
     if (n_segs == 0) return;
     const uint32_t N = max_n + 1;
-    dim3 g1((N + LCP_THREADS - 1) / LCP_THREADS, n_segs);
-    hipLaunchKernelGGL(lcp_kernel, g1, dim3(LCP_THREADS), 0, stream, d_segs, ix);
+    const uint32_t gx = (N + LCP_THREADS - 1) / LCP_THREADS;
+    hipLaunchKernelGGL(lcp_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(LCP_THREADS), 0, stream, d_segs, n_segs, gx, ix);
     const uint32_t nb1 = (N + 63) / 64;
     dim3 g2((nb1 + 63) / 64, n_segs);
     hipLaunchKernelGGL(bmin2_kernel, g2, dim3(64), 0, stream, d_segs, ix);
