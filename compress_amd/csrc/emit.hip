@@ -39,7 +39,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs,
                                                                 const uint32_t *res, uint8_t *adv_out, uint8_t *kind_out,
                                                                 uint8_t *exit_out, uint16_t *bits_out) {
     static_assert(DECIDE_THREADS == TILE, "one thread per position of a tile");
-    __shared__ uint16_t s_j[2][TILE], s_b[2][TILE];
+    __shared__ uint32_t s_pb[2][TILE];
     const Seg sg = segs[blockIdx.y];
     const int n = (int)sg.n;
     const int tbase = (int)(blockIdx.x * TILE), tend = tbase + TILE;
@@ -96,17 +96,17 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs,
         p = nx >= tend ? (uint32_t)(TILE + nx - tend) : (nx >= n ? (uint32_t)TILE : (uint32_t)(nx - tbase));
         bits = kind_bits(kind);
     }
+    // one word per position: chain state in the low half, bits so far in the high half (<= 9539 bits per tile)
     int cur = 0;
-    s_j[0][x] = (uint16_t)p;
-    s_b[0][x] = (uint16_t)bits;
+    s_pb[0][x] = p | (bits << 16);
     __syncthreads();
     for (int k = 0; k < 8; ++k) {
         if (p < (uint32_t)TILE) {
-            bits += s_b[cur][p];
-            p = s_j[cur][p];
+            const uint32_t v = s_pb[cur][p];
+            bits += v >> 16;
+            p = v & 0xFFFFu;
         }
-        s_j[cur ^ 1][x] = (uint16_t)p;
-        s_b[cur ^ 1][x] = (uint16_t)bits;
+        s_pb[cur ^ 1][x] = p | (bits << 16);
         cur ^= 1;
         if (__syncthreads_count(p < (uint32_t)TILE) == 0) break;
     }
