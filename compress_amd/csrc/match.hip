@@ -451,13 +451,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
             k = done ? k : k + 4;
         }
         MP(1)
-        for (uint64_t hm = __ballot(!done); hm; hm &= hm - 1) {  // the wave finishes lane t's walk
+        for (uint64_t hm = (ablate & 16) ? 0ull : __ballot(!done); hm; hm &= hm - 1) {  // the wave finishes lane t's walk
             const int t = (int)__builtin_ctzll(hm);
             const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
             int cm = __shfl(m, t);
             bool cfL = __shfl((int)(qupL != NONE_UP), t) != 0;
             uint32_t rL = NONE_UP, rS = NONE_UP;
+            DS(11, 1)
             for (int base = __shfl(k, t); base < N; base += 64) {
+                DS(12, 1)
                 const int kk = base + lane;
                 const bool valid = kk < N;
                 const int l = valid ? (int)LCP[kk] : 0;
@@ -526,13 +528,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
             done = true;
         }
         MP(3)
-        for (uint64_t hm = __ballot(!done); hm; hm &= hm - 1) {
+        for (uint64_t hm = (ablate & 16) ? 0ull : __ballot(!done); hm; hm &= hm - 1) {
             const int t = (int)__builtin_ctzll(hm);
             const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
             int cm = __shfl(m, t);
             bool cfL = __shfl((int)(qdnL != NONE_DN), t) != 0;
             uint32_t rL = NONE_DN, rS = NONE_DN;
+            DS(13, 1)
             for (int base = __shfl(k, t); base >= 1; base -= 64) {
+                DS(14, 1)
                 const int kk = base - lane;
                 const bool valid = kk >= 1;
                 const int l = valid ? (int)LCP[kk + 1] : 0;

@@ -16,7 +16,7 @@ f(buf, 1)
 bt.compress()
 f(buf, 1)
 names = ["lookups", "bucket_miss", "probes", "probe_ties", "tie_bytes+8", "final_text_compares", "final_steps", "pd_searches",
-         "bracket_sum", "Ld_sum", "bracket2_sum"]
+         "bracket_sum", "Ld_sum", "bracket2_sum", "coop_up_lanes x64", "coop_up_steps x64", "coop_dn_lanes x64", "coop_dn_steps x64"]
 n = max(buf[0], 1)
 for k, nm in enumerate(names):
     print("%-20s %12d  %8.3f per lookup" % (nm, buf[k], buf[k] / n))
