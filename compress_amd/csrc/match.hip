@@ -137,9 +137,11 @@ void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchI
 // different keys also give the exact common prefix length (key_lcp) - so on zero-heavy data, where a plain 8-byte
 // prefix ties on every probe and every tie costs a text compare, almost every probe is decided by one load.
 constexpr int DICT_RUN_CAP = 254;
-// run: the length of the run of s[0] at s if the caller knows it (the text's `rlen`, capped at 255; it may exceed A), else < 0
-__device__ inline uint64_t run_key(const uint8_t *s, int A, int &rlc, int run = -1) {
-    const uint32_t c = s[0];
+// run: the length of the run of s[0] at s if the caller knows it (the text's `rlen`, capped at 255; it may exceed A), else < 0.
+// w0: the first 8 bytes of s (little-endian load); a run of up to 3 leaves the whole tail inside it, so the common
+// case costs no load of its own
+__device__ inline uint64_t run_key_w(const uint8_t *s, int A, int &rlc, int run, uint64_t w0) {
+    const uint32_t c = (uint32_t)(w0 & 0xFFull);
     const int lim = (A - 1) < DICT_RUN_CAP ? (A - 1) : DICT_RUN_CAP;
     const int rl = run < 0 ? 1 + lcp_bytes(s, s + 1, 0, lim) : (run < lim + 1 ? run : lim + 1);
     if (rl >= DICT_RUN_CAP) {
@@ -151,14 +153,15 @@ __device__ inline uint64_t run_key(const uint8_t *s, int A, int &rlc, int run = 
     bool falling = true;
     if (rl < A) {
         const int avail = A - rl;
-        const uint64_t w = ld8(s + rl);
-        tail = __builtin_bswap64(w) >> 24;
+        const uint64_t w = rl <= 3 ? (w0 >> (8 * rl)) : ld8(s + rl);
+        tail = (__builtin_bswap64(w) >> 24) & ((1ull << 40) - 1ull);
         if (avail < 5) tail &= ~((1ull << (8 * (5 - avail))) - 1ull);
         falling = (uint32_t)(w & 0xFFull) < c;
     }
     const uint64_t code = falling ? (uint64_t)rl : (uint64_t)(511 - rl);
     return ((uint64_t)c << 49) | (code << 40) | tail;
 }
+__device__ inline uint64_t run_key(const uint8_t *s, int A, int &rlc) { return run_key_w(s, A, rlc, -1, ld8(s)); }
 // common prefix length of two strings from their (different) keys; the caller caps it by the strings' lengths
 __device__ inline int key_lcp(uint64_t a, uint64_t b) {
     if ((a ^ b) >> 49) return 0;
@@ -262,8 +265,8 @@ __device__ inline void dict_search(const DictView &D, const uint8_t *pat, int ma
 }
 
 // the bracket of every suffix sharing two bytes with pat; false if there is none
-__device__ inline bool dict_bucket(const DictView &D, const uint8_t *pat, int &lo, int &hi) {
-    const uint32_t b = ((uint32_t)pat[0] << 8) | pat[1];
+__device__ inline bool dict_bucket(const DictView &D, uint64_t w0, int &lo, int &hi) {
+    const uint32_t b = ((uint32_t)(w0 & 0xFFull) << 8) | (uint32_t)((w0 >> 8) & 0xFFull);
     const int s = D.bstart[b], e = D.bend[b];
     if (s >= e) return false;
     lo = lo > s - 1 ? lo : s - 1;
@@ -273,17 +276,17 @@ __device__ inline bool dict_bucket(const DictView &D, const uint8_t *pat, int &l
 
 // Longest prefix of pat[0:maxLen) occurring in the dictionary (Ld) and a rank kd that attains it, searched inside the
 // bracket [lo, hi] (0, n + 1 for the whole dictionary).  minLen: shorter results are of no use to the caller (lets an
-// empty two-byte bucket end the search).  run: the text's run length at pat, if known.  The occurrence itself
+// empty two-byte bucket end the search).  run: the text's run length at pat, if known; w0: the first 8 bytes of pat.  The occurrence itself
 // (dict_occurrence) is only needed for a reference that is written.
 __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int maxLen, int minLen, int lo, int hi, int &Ld,
-                                   int &kd, int run MP_ARG) {
+                                   int &kd, int run, uint64_t w0 MP_ARG) {
     Ld = 0;
     kd = 0;
     DS(0, 1)
-    if (maxLen >= 2 && !dict_bucket(D, pat, lo, hi) && minLen >= 2) { DS(1, 1) return; }  // nothing shares two bytes with pat
+    if (maxLen >= 2 && !dict_bucket(D, w0, lo, hi) && minLen >= 2) { DS(1, 1) return; }  // nothing shares two bytes with pat
     DS(8, hi - lo)
     int prl;
-    const uint64_t pk = run_key(pat, maxLen, prl, run);
+    const uint64_t pk = run_key_w(pat, maxLen, prl, run, w0);
     if (prl >= 2) {  // inside a run the two-byte bucket is huge (zero-heavy data): narrow to the suffixes with the same run code
         const uint32_t kt = (uint32_t)(pk >> 40);
         const int s = D.bstart[DICT_PAIR_BUCKETS + kt], e = D.bend[DICT_PAIR_BUCKETS + kt];
@@ -330,12 +333,6 @@ __device__ inline uint32_t select_backref(const DictView &D, int i, int minD, bo
     if (Ls > 0 && Ls >= Ldyn) return res_pack(RES_SHORT, (uint32_t)Ls, (uint32_t)(i - ps - 1));
     if (Ldyn > 0) return res_pack(RES_DYN, (uint32_t)Ldyn, fdyn);
     return res_pack(RES_NONE, 0, 0);
-}
-
-// true when the walk can never call bestBackref(i): i, i-1 and i-2 lie in one run of equal bytes and at
-// least 160 of them follow i, so the RLE branch (compress.go:184) is taken at i, i-1 and i-2
-__device__ inline bool never_queried(const uint8_t *RL, int i) {
-    return i >= 2 && RL[i - 2] >= LZSS_MIN_REPEAT + 2;  // run lengths of the suffix sort, capped at 255
 }
 
 #ifndef MATCH_SCAN_CAP
@@ -405,12 +402,22 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
         i = s_sa[WIN_HALO + lane];
         work = !(i < (int)sg.start || i < HEAD);
     }
-    if (work && skip_unqueried && never_queried(ix.rlen + sg.off, i)) {
+    // the lane's own scattered reads, issued together: the first 8 text bytes (reserved-symbol test, dictionary bucket
+    // and key) and the run lengths at i - 2 .. i + 1 (RLE skip test, dictionary key)
+    uint64_t w0 = 0;
+    uint32_t rl4 = 0;
+    if (work) {  // i >= HEAD > 2
+        w0 = ld8(T + i);
+        __builtin_memcpy(&rl4, ix.rlen + sg.off + i - 2, 4);
+    }
+    // the walk can never call bestBackref(i) when i, i-1 and i-2 lie in one run of equal bytes and at least 160 of them
+    // follow i: the RLE branch (compress.go:184) is taken at i, i-1 and i-2 (run lengths capped at 255)
+    if (work && skip_unqueried && (rl4 & 0xFFu) >= LZSS_MIN_REPEAT + 2) {
         res[sg.off + i] = res_pack(RES_NONE, 0, 0);
         work = false;
     }
     const int maxLen = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
-    const bool reserved = work && T[i] >= LZSS_SYMBOL_SHORT;
+    const bool reserved = work && (w0 & 0xFFull) >= LZSS_SYMBOL_SHORT;
     const int minS = reserved ? 1 : LZSS_SHORT_MIN_LEN;
     const int minD = reserved ? 1 : LZSS_DYN_MIN_LEN;
     const bool shortOK = maxLen >= minS, dynOK = maxLen >= minD;
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     // wave - their lower bounds are monotone in rank - was measured slower: the phases serialise the probe latency
     // and a divergent probe loop costs the same issue slots however few lanes run it.)
     int Ld = 0, kd = 0;
-    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, kd, (int)ix.rlen[sg.off + i] MP_PASS);
+    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, kd, (int)((rl4 >> 16) & 0xFFu), w0 MP_PASS);
     MP(7)
     // selection (compress.go:160-169) BEFORE the offsets: only the window whose reference is emitted needs its
     // smallest-rank occurrence, so every lane runs at most one interval search
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(64) void match_head_kernel(const Seg *segs, BatchIn
     const int Ls = best, ps = bp;
     const int LL = (dynOK && best >= minD) ? best : 0, pL = bp;
     int Ld = 0, kd = 0, pd = -1;
-    if (dynOK && LL < maxLen) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, kd, (int)RL[i] MP_NONE);  // compress.go:460
+    if (dynOK && LL < maxLen) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, kd, (int)RL[i], ld8(T + i) MP_NONE);  // compress.go:460
     if (Ld >= minD && Ld > LL) pd = dict_occurrence(D, kd, Ld);
     res[sg.off + i] = select_backref(D, i, minD, dynOK, Ls, ps, LL, pL, Ld, pd);
 }
