@@ -88,7 +88,7 @@ struct mi355_lzss_ctx {
     std::vector<uint8_t> dict;  // augmented
     int32_t res_idx[2] = {0, 0};
     // dictionary index on the device
-    DevBuf d_text, d_sa, d_isa, d_lcp, d_b1, d_b2, d_key, d_bstart, d_bend;
+    DevBuf d_text, d_sa, d_isa, d_lcp, d_b1, d_b2, d_key, d_bkt;
     DictView view{};
     mi355_lzss_batch *scratch = nullptr;  // for the single-buffer entry points
     // side streams + events for running the index / match stages of sub-batches concurrently
@@ -545,12 +545,11 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     CP(d_b1, b1, (stride / 64 + 1) * 2) CP(d_b2, b2, (stride / 64 + 1) * 2)
 #undef CP
     if ((rc = ctx->d_key.ensure(stride * 8)) != 0) return bail(rc);
-    if ((rc = ctx->d_bstart.ensure(DICT_BUCKETS * 4)) != 0) return bail(rc);
-    if ((rc = ctx->d_bend.ensure(DICT_BUCKETS * 4)) != 0) return bail(rc);
-    if (hipMemsetAsync(ctx->d_bstart.p, 0, DICT_BUCKETS * 4, sm) != hipSuccess || hipMemsetAsync(ctx->d_bend.p, 0, DICT_BUCKETS * 4, sm) != hipSuccess)
+    if ((rc = ctx->d_bkt.ensure(DICT_BUCKETS * 8)) != 0) return bail(rc);
+    if (hipMemsetAsync(ctx->d_bkt.p, 0, DICT_BUCKETS * 8, sm) != hipSuccess)
         return bail(fail(MI355_LZSS_E_DEVICE, "hipMemsetAsync failed"));
     launch_dict_aux(ctx->d_text.as<uint8_t>(), (uint32_t)aug.size(), ctx->d_sa.as<int32_t>(), ctx->d_key.as<uint64_t>(),
-                    ctx->d_bstart.as<int32_t>(), ctx->d_bend.as<int32_t>(), sm);
+                    ctx->d_bkt.as<int32_t>(), sm);
     if (hipStreamSynchronize(sm) != hipSuccess || hipGetLastError() != hipSuccess)
         return bail(fail(MI355_LZSS_E_DEVICE, "building the dictionary index failed: %s", hipGetErrorString(hipGetLastError())));
     ctx->view.T = ctx->d_text.as<uint8_t>();
@@ -560,8 +559,7 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     ctx->view.bmin1 = ctx->d_b1.as<uint16_t>();
     ctx->view.bmin2 = ctx->d_b2.as<uint16_t>();
     ctx->view.key = ctx->d_key.as<uint64_t>();
-    ctx->view.bstart = ctx->d_bstart.as<int32_t>();
-    ctx->view.bend = ctx->d_bend.as<int32_t>();
+    ctx->view.bkt = ctx->d_bkt.as<int2>();
     *out = ctx;
     return 0;
 }
@@ -576,7 +574,7 @@ extern "C" void mi355_lzss_ctx_destroy(mi355_lzss_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->scratch) mi355_lzss_batch_destroy(ctx->scratch);
-    DevBuf *bufs[] = {&ctx->d_text, &ctx->d_sa, &ctx->d_isa, &ctx->d_lcp, &ctx->d_b1, &ctx->d_b2, &ctx->d_key, &ctx->d_bstart, &ctx->d_bend};
+    DevBuf *bufs[] = {&ctx->d_text, &ctx->d_sa, &ctx->d_isa, &ctx->d_lcp, &ctx->d_b1, &ctx->d_b2, &ctx->d_key, &ctx->d_bkt};
     for (DevBuf *d : bufs) d->release();
     for (int k = 0; k < mi355_lzss_ctx::kMaxSplit; ++k) {
         if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);

@@ -26,15 +26,13 @@ struct DictView {     // the dictionary index of a ctx (device pointers)
     const int32_t *SA;
     const uint16_t *LCP, *bmin1, *bmin2;
     const uint64_t *key;       // [rank] first 8 bytes of the suffix, big-endian, zero padded
-    const int32_t *bstart;     // [first two bytes] rank range [bstart, bend) of the suffixes starting with them
-    const int32_t *bend;
+    const int2 *bkt;           // rank range [x, y) of the suffixes of a bucket (DICT_BUCKETS entries, see below)
 };
 // rank range tables of the dictionary: [0, 65536) by the first two bytes, then 2^17 entries by the top 17 bits of the
 // run-aware key (first byte, run code)
 constexpr uint32_t DICT_PAIR_BUCKETS = 65536, DICT_BUCKETS = 65536 + (1u << 17);
-// fills key / bstart / bend (DICT_BUCKETS entries each, must be zeroed) from the dictionary's text and suffix array
-void launch_dict_aux(const uint8_t *d_text, uint32_t n, const int32_t *d_sa, uint64_t *d_key, int32_t *d_bstart,
-                     int32_t *d_bend, hipStream_t stream);
+// fills key / bkt (DICT_BUCKETS pairs, must be zeroed) from the dictionary's text and suffix array
+void launch_dict_aux(const uint8_t *d_text, uint32_t n, const int32_t *d_sa, uint64_t *d_key, int32_t *d_bkt, hipStream_t stream);
 struct BatchIndex {   // batch-wide index arrays
     const uint8_t *text;
     int32_t *sa, *isa;

@@ -176,7 +176,7 @@ __device__ inline int key_lcp(uint64_t a, uint64_t b) {
 // Auxiliary arrays of the dictionary index: a run-aware 8-byte key per rank (one load decides almost every probe
 // of the binary search) and the rank range of every two-byte prefix (skips the first probes altogether).
 __global__ __launch_bounds__(256) void dict_aux_kernel(const uint8_t *T, uint32_t n, const int32_t *SA, uint64_t *key,
-                                                       int32_t *bstart, int32_t *bend) {
+                                                       int32_t *bkt) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;  // rank, 0 = sentinel
     if (k > n) return;
     const uint32_t q = (uint32_t)SA[k];
@@ -195,36 +195,32 @@ __global__ __launch_bounds__(256) void dict_aux_kernel(const uint8_t *T, uint32_
             const uint32_t qn = (uint32_t)SA[k + 1];
             last = (uint32_t)(run_key(T + qn, (int)(n - qn), rlc) >> 40) != kt;
         }
-        if (first) bstart[DICT_PAIR_BUCKETS + kt] = (int32_t)k;
-        if (last) bend[DICT_PAIR_BUCKETS + kt] = (int32_t)k + 1;
+        if (first) bkt[2 * (DICT_PAIR_BUCKETS + kt)] = (int32_t)k;
+        if (last) bkt[2 * (DICT_PAIR_BUCKETS + kt) + 1] = (int32_t)k + 1;
     }
     if (q + 2 > n) return;
     const uint32_t b = ((uint32_t)T[q] << 8) | T[q + 1];
     const uint32_t qp = (uint32_t)SA[k - 1];
     const bool first = (k == 1) || qp + 2 > n || ((((uint32_t)T[qp] << 8) | T[qp + 1]) != b);
-    if (first) bstart[b] = (int32_t)k;
+    if (first) bkt[2 * b] = (int32_t)k;
     bool last = (k == n);
     if (!last) {
         const uint32_t qn = (uint32_t)SA[k + 1];
         last = qn + 2 > n || ((((uint32_t)T[qn] << 8) | T[qn + 1]) != b);
     }
-    if (last) bend[b] = (int32_t)k + 1;
+    if (last) bkt[2 * b + 1] = (int32_t)k + 1;
 }
 
-void launch_dict_aux(const uint8_t *d_text, uint32_t n, const int32_t *d_sa, uint64_t *d_key, int32_t *d_bstart,
-                     int32_t *d_bend, hipStream_t stream) {
-    hipLaunchKernelGGL(dict_aux_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, stream, d_text, n, d_sa, d_key, d_bstart,
-                       d_bend);
+void launch_dict_aux(const uint8_t *d_text, uint32_t n, const int32_t *d_sa, uint64_t *d_key, int32_t *d_bkt, hipStream_t stream) {
+    hipLaunchKernelGGL(dict_aux_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, stream, d_text, n, d_sa, d_key, d_bkt);
 }
 
 // exact common prefix of pat[0:maxLen) and the dictionary suffix of rank k (0 for the sentinel / virtual ranks):
 // from the keys when they differ, else by comparing text past the run the equal keys vouch for
-__device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int k) {
-    if (k < 1 || k > (int)D.n) return 0;
-    const int q = D.SA[k];
+__device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int k, int q, uint64_t kq) {
+    if (k < 1 || k > (int)D.n) return 0;  // q = SA[k], kq = key[k] (whatever the arrays hold for the virtual rank n + 1)
     const int avail = (int)D.n - q;
     const int lim = maxLen < avail ? maxLen : avail;
-    const uint64_t kq = D.key[k];
     if (kq != pk) {
         const int l = key_lcp(pk, kq);
         return l < lim ? l : lim;
@@ -267,7 +263,8 @@ __device__ inline void dict_search(const DictView &D, const uint8_t *pat, int ma
 // the bracket of every suffix sharing two bytes with pat; false if there is none
 __device__ inline bool dict_bucket(const DictView &D, uint64_t w0, int &lo, int &hi) {
     const uint32_t b = ((uint32_t)(w0 & 0xFFull) << 8) | (uint32_t)((w0 >> 8) & 0xFFull);
-    const int s = D.bstart[b], e = D.bend[b];
+    const int2 se = D.bkt[b];  // one load for both ends
+    const int s = se.x, e = se.y;
     if (s >= e) return false;
     lo = lo > s - 1 ? lo : s - 1;
     hi = hi < e ? hi : e;
@@ -289,7 +286,8 @@ __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int ma
     const uint64_t pk = run_key_w(pat, maxLen, prl, run, w0);
     if (prl >= 2) {  // inside a run the two-byte bucket is huge (zero-heavy data): narrow to the suffixes with the same run code
         const uint32_t kt = (uint32_t)(pk >> 40);
-        const int s = D.bstart[DICT_PAIR_BUCKETS + kt], e = D.bend[DICT_PAIR_BUCKETS + kt];
+        const int2 se = D.bkt[DICT_PAIR_BUCKETS + kt];
+        const int s = se.x, e = se.y;
         if (s < e) {  // the key order is the suffix order: the pattern's lower bound lies in [s, e]
             lo = lo > s - 1 ? lo : s - 1;
             hi = hi < e ? hi : e;
@@ -299,8 +297,13 @@ __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int ma
     MP(12)
     dict_search(D, pat, maxLen, pk, prl, lo, hi);
     MP(13)
-    const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo);
-    const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi);
+    // hi == lo + 1: the suffix-array entries and the keys of both ends come with one load each
+    int q2[2];
+    uint64_t k2[2];
+    __builtin_memcpy(q2, D.SA + lo, 8);
+    __builtin_memcpy(k2, D.key + lo, 16);
+    const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo, q2[0], k2[0]);
+    const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi, q2[1], k2[1]);
     Ld = llo > lhi ? llo : lhi;
     MP(14)
     DS(9, Ld)
