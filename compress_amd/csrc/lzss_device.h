@@ -139,12 +139,14 @@ __device__ inline int lcp_run(const uint8_t *T, const uint8_t *RL, uint32_t a, u
 
 // lcp_run for the LCP array (neighbours in rank: the first bytes are nearly always equal): the first 8 text bytes
 // and the run lengths of both suffixes are fetched in ONE round trip; they settle the first-byte test, unequal runs
-// and every prefix shorter than 8, so only longer prefixes pay for a compare loop.  (32 bytes per compare step was
+// and every prefix shorter than 8, so only longer prefixes pay for a compare loop; and rank k's upper suffix is rank
+// k - 1's lower one, so a lane fetches its own suffix only and takes the other from its neighbour lane.  (32 bytes per compare step was
 // measured slower: this kernel is bound by the number of scattered loads, not by the length of their chain.)
-__device__ inline int lcp_run_rank(const uint8_t *T, const uint8_t *RL, uint32_t a, uint32_t b, int lim) {
+// wa / wb: the first 8 text bytes at a / b, ra / rb: the run lengths there (the caller has them: a lane's a is its
+// neighbour's b)
+__device__ inline int lcp_run_rank(const uint8_t *T, uint32_t a, uint32_t b, uint64_t wa, uint64_t wb, int ra, int rb, int lim) {
     if (lim <= 0) return 0;
-    const uint64_t x = ld8(T + a) ^ ld8(T + b);
-    const int ra = RL[a], rb = RL[b];
+    const uint64_t x = wa ^ wb;
     if (x & 0xFFull) return 0;
     const int r = ra < rb ? ra : rb;
     if (ra != rb) return r < lim ? r : lim;

@@ -72,15 +72,29 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint3
     const int32_t *SA = ix.sa + sg.off;
     uint32_t l = 0xFFFFu;
     int sak = INT_MAX;
+    uint64_t wb = 0;
+    int rb = 0;
+    if (k < N) {  // the sentinel's "text" is the zero padding
+        sak = SA[k];
+        wb = ld8(T + sak);
+        rb = RL[sak];
+    }
+    // the upper suffix of the pair is the neighbour lane's; the first lane of a wave fetches it
+    int a = __shfl_up(sak, 1);
+    uint64_t wa = __shfl_up(wb, 1);
+    int ra = __shfl_up(rb, 1);
+    if ((threadIdx.x & 63) == 0 && k > 0 && k < N) {
+        a = SA[k - 1];
+        wa = ld8(T + a);
+        ra = RL[a];
+    }
     if (k < N) {
         l = 0;
-        sak = SA[k];
         if (k > 0) {
-            const uint32_t a = (uint32_t)SA[k - 1], b = (uint32_t)sak;
-            const uint32_t hi = a > b ? a : b;
+            const uint32_t hi = (uint32_t)(a > sak ? a : sak);
             int lim = (int)(sg.n - hi);  // the shorter suffix ends at the sentinel
             if (lim > LZSS_MAX_LEN) lim = LZSS_MAX_LEN;
-            l = (uint32_t)lcp_run_rank(T, RL, a, b, lim);
+            l = (uint32_t)lcp_run_rank(T, (uint32_t)a, (uint32_t)sak, wa, wb, ra, rb, lim);
         }
         ix.lcp[sg.off + k] = (uint16_t)l;
         if (k == N - 1)  // the upward walk of match_kernel reads up to three ranks past N and must die there
