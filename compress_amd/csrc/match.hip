@@ -629,7 +629,10 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     if (short_wins || long_wins) {
         const bool up = short_wins ? upS : upL;
         const int kdn = short_wins ? kdnS : kdnL;
-        if (up) p = SA[short_wins ? kupS : kupL];
+        if (up) {  // mostly still inside the staged window
+            const int ku = short_wins ? kupS : kupL;
+            p = (ku - wbase < WIN_TOTAL) ? s_sa[ku - wbase] : SA[ku];
+        }
         else if (defer) { pending = true; p = kdn; }
         else if (ablate & 2) p = SA[kdn];
         else p = leftmost(S, kdn, short_wins ? Ls : LL, short_wins ? wsS : wsL, i, short_wins MP_PASS);
