@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-PMC_FILE = "r01_e_pmc_hbm_traffic.csv"
+PMC_FILE = "r01_f_pmc_hbm_traffic.csv"
 
 
 def pmc_traffic(stage, n_blobs):
