@@ -633,6 +633,9 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
             const int ku = short_wins ? kupS : kupL;
             p = (ku - wbase < WIN_TOTAL) ? s_sa[ku - wbase] : SA[ku];
         }
+        else if (kdn >= wbase && (int)s_lc[kdn - wbase] < (short_wins ? Ls : LL)) {
+            p = s_sa[kdn - wbase];  // rank kdn - 1 shares fewer bytes: kdn is the first rank of the interval, hence the answer
+        }
         else if (defer) { pending = true; p = kdn; }
         else if (ablate & 2) p = SA[kdn];
         else p = leftmost(S, kdn, short_wins ? Ls : LL, short_wins ? wsS : wsL, i, short_wins MP_PASS);
