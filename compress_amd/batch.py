@@ -65,7 +65,9 @@ class Batch:
         return res
 
     def results(self, blob: int):
-        """packed per-position results of blob (type<<30 | len<<21 | field)"""
+        """RAW packed per-position results of blob: type<<30 | pending<<29 | (len-1)<<21 | field.  After
+        compress() the field of a pending entry is a suffix rank and that of a type-3 entry a dictionary rank
+        (include/mi355_lzss.h); Compressor.best_backrefs gives the reference's (type, address, length)."""
         n = self.lens[blob]
         packed = np.zeros(max(n, 1), dtype=np.uint32)
         _check(_lib.lib().mi355_lzss_batch_results(self.h, blob, _ptr(packed), n))

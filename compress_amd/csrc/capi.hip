@@ -418,17 +418,18 @@ extern "C" int mi355_lzss_batch_download(mi355_lzss_batch *b, uint8_t *out, cons
     int rc;
     if ((rc = set_device(b->ctx)) != 0) return rc;
     const uint64_t total = b->n_blobs ? b->h_out_off[b->n_blobs] : 0;
-    if (total == 0) return 0;
-    if ((rc = b->h_stage.ensure((size_t)total)) != 0) return rc;
-    hipStream_t sm = b->ctx->stream;
-    HIP_TRY(hipMemcpyAsync(b->h_stage.p, b->out.p, (size_t)total, hipMemcpyDeviceToHost, sm));
-    HIP_TRY(hipStreamSynchronize(sm));
+    if (total) {
+        if ((rc = b->h_stage.ensure((size_t)total)) != 0) return rc;
+        hipStream_t sm = b->ctx->stream;
+        HIP_TRY(hipMemcpyAsync(b->h_stage.p, b->out.p, (size_t)total, hipMemcpyDeviceToHost, sm));
+        HIP_TRY(hipStreamSynchronize(sm));
+    }
     int worst = 0;
-    for (uint32_t k = 0; k < b->n_blobs; ++k) {
+    for (uint32_t k = 0; k < b->n_blobs; ++k) {  // also with nothing to copy: every blob gets its status
         int32_t st = b->h_pre_status[k] ? b->h_pre_status[k] : b->h_status[k];
         const uint64_t cap = out_off[k + 1] - out_off[k];
         if (st == 0 && b->h_out_len[k] > cap) st = MI355_LZSS_E_CAPACITY;
-        if (st == 0) memcpy(out + out_off[k], b->h_stage.as<uint8_t>() + b->h_out_off[k], b->h_out_len[k]);
+        if (st == 0 && b->h_out_len[k]) memcpy(out + out_off[k], b->h_stage.as<uint8_t>() + b->h_out_off[k], b->h_out_len[k]);
         if (status) status[k] = st;
         if (st && !worst) worst = st;
     }
@@ -671,9 +672,17 @@ extern "C" int mi355_lzss_compress_batch(mi355_lzss_ctx *ctx, const uint8_t *in,
     mi355_lzss_batch *b = ctx->scratch;
     if ((rc = mi355_lzss_batch_upload(b, in, in_off, n_blobs, nullptr)) != 0) return rc;
     if ((rc = mi355_lzss_batch_compress(b, 1)) != 0) return rc;
-    if (out_len)
-        for (uint32_t k = 0; k < n_blobs; ++k) out_len[k] = b->h_out_len[k];
-    return mi355_lzss_batch_download(b, out, out_off, status);
+    std::vector<int32_t> st(n_blobs ? n_blobs : 1, 0);
+    rc = mi355_lzss_batch_download(b, out, out_off, st.data());
+    int worst = 0;
+    for (uint32_t k = 0; k < n_blobs; ++k) {  // a failed blob has no length
+        if (out_len) out_len[k] = (rc == 0 && st[k] == 0) ? b->h_out_len[k] : 0;
+        if (status) status[k] = st[k];
+        if (st[k] && !worst) worst = st[k];
+    }
+    if (rc != 0) return rc;
+    if (worst && !status) return fail(worst, "blob failed with status %d", worst);
+    return 0;
 }
 
 // ---- decompression: see decompress.hip ----------------------------------------------------------------------

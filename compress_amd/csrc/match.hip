@@ -701,10 +701,15 @@ void launch_match_head(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const
 void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
                   uint32_t *d_res, bool skip_unqueried, hipStream_t stream) {
     if (n_segs == 0 || max_n <= (uint32_t)HEAD) return;
-    static const int ablate = getenv("MI355_LZSS_ABLATE") ? atoi(getenv("MI355_LZSS_ABLATE")) : 0;  // timing experiments only
+#ifdef LZSS_DEBUG_KNOBS  // timing experiments only (scripts/build_variants.sh); the shipped library ignores the environment
+    static const int ablate = getenv("MI355_LZSS_ABLATE") ? atoi(getenv("MI355_LZSS_ABLATE")) : 0;
+    static const bool no_defer = getenv("MI355_LZSS_NO_DEFER") != nullptr;
+#else
+    constexpr int ablate = 0;
+    constexpr bool no_defer = false;
+#endif
     const uint32_t gx = (max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS;  // blocks per segment
     // for_emit: the results feed the phrase walk and the emitter only (not the per-position debug view)
-    static const bool no_defer = getenv("MI355_LZSS_NO_DEFER") != nullptr;  // timing experiments only
     const int defer = (skip_unqueried && !no_defer && max_n + 1 < RES_DEFER_MAX_N) ? 1 : 0;
     hipLaunchKernelGGL(match_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(MATCH_THREADS), 0, stream, d_segs, n_segs, gx,
                        ix, dict, d_res, skip_unqueried ? 1 : 0, defer, ablate);

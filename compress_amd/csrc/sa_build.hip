@@ -1,5 +1,5 @@
-// sa_build.hip - suffix array + inverse of every segment of a batch, one 1024-thread workgroup per
-// segment (gfx950).  Replaces suffixarray.New (lzss/internal/suffixarray/suffixarray.go:32-45, which
+// sa_build.hip - suffix array + inverse of every segment of a batch, one workgroup per segment (gfx950):
+// 512 threads in the main kernel (two workgroups per CU), 1024 in the fallback for texts of 512 KiB and more.  Replaces suffixarray.New (lzss/internal/suffixarray/suffixarray.go:32-45, which
 // runs SA-IS, sais.go:128-203) for both the input index (lzss/compress.go:116) and the dictionary
 // index (compress.go:64).  The suffix array of a text is a unique object, so the construction is
 // free to be GPU-shaped: prefix doubling (Manber-Myers bucket induction), every round one stable
@@ -1176,7 +1176,11 @@ void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, con
 void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
                      hipStream_t stream) {
     if (n_segs == 0) return;
-    static const int max_rounds = getenv("MI355_LZSS_SA_ROUNDS") ? atoi(getenv("MI355_LZSS_SA_ROUNDS")) : 1000;  // timing experiments only
+#ifdef LZSS_DEBUG_KNOBS  // timing experiments only (scripts/build_variants.sh); the shipped library ignores the environment
+    static const int max_rounds = getenv("MI355_LZSS_SA_ROUNDS") ? atoi(getenv("MI355_LZSS_SA_ROUNDS")) : 1000;
+#else
+    constexpr int max_rounds = 1000;
+#endif
     const uint32_t N = max_n + 1;
     static bool attr_set = false;  // both instantiations may use more than the default 64 KiB of dynamic LDS
     if (!attr_set) {

@@ -107,8 +107,15 @@ int  mi355_lzss_batch_sizes(mi355_lzss_batch *b, uint32_t *out_len, uint64_t *nb
 /* HBM -> host: compressed blobs into out[out_off[b]:out_off[b+1]) */
 int  mi355_lzss_batch_download(mi355_lzss_batch *b, uint8_t *out, const uint64_t *out_off,
                                int32_t *status);
-/* per-position results of the last run for blob `blob` (packed: bits 30-31 type (1 short,
- * 2 long), bits 21-29 length, bits 0-20 offset field); n entries */
+/* RAW per-position results of the last run for blob `blob`, n entries (diagnostic).  Packed:
+ * bits 30-31 type (0 none, 1 short, 2 long, 3 long into the dictionary), bit 29 PENDING,
+ * bits 21-28 length - 1, bits 0-20 field.  field = the address bits as written (backref.go:66)
+ * ONLY for a type 1 / 2 entry without the PENDING bit.  batch_compress leaves the address search
+ * of most entries to the emitter: a PENDING entry's field is the suffix RANK that search starts
+ * from, a type 3 entry's field is a DICTIONARY rank, and positions the phrase walk never asks
+ * about (inside runs of 160+ equal bytes, compress.go:180-218) read as type 0.  Lengths and types
+ * 1 / 2 are final.  For the reference's (type, address, length) of every position use
+ * mi355_lzss_best_backrefs. */
 int  mi355_lzss_batch_results(mi355_lzss_batch *b, uint32_t blob, uint32_t *packed, size_t n);
 /* suffix array / inverse / lcp of blob `blob` from the last run (diagnostics for parity tests;
  * n+1 entries each: rank 0 is the end sentinel) */
