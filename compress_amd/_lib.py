@@ -18,6 +18,7 @@ SIGNATURES = {
     "mi355_lzss_dict_info": (_i32, [_vp, C.POINTER(_u64), C.POINTER(C.c_int32 * 2)]),
     "mi355_lzss_best_backrefs": (_i32, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "mi355_lzss_write": (_i32, [_vp, _vp, _sz, _sz, C.c_uint, _vp, _sz, C.POINTER(_u64)]),
+    "mi355_lzss_write_noalloc": (_i32, [_vp, _vp, _sz, _sz, C.c_uint, _vp, _sz, _vp, _vp, _vp]),
     "mi355_lzss_compressed_size": (_i32, [_vp, _vp, _sz, C.POINTER(_u64)]),
     "mi355_lzss_compress_batch": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "mi355_lzss_decompress_batch": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -91,6 +92,7 @@ struct mi355_lzss_ctx {
     DevBuf d_text, d_sa, d_isa, d_lcp, d_b1, d_b2, d_key, d_bkt;
     DictView view{};
     mi355_lzss_batch *scratch = nullptr;  // for the single-buffer entry points
+    mi355_lzss_batch *na = nullptr;       // view of this device's static scratch array (mi355_lzss_write_noalloc)
     // side streams + events for running the index / match stages of sub-batches concurrently
     static constexpr int kMaxSplit = 4;
     hipStream_t side[kMaxSplit] = {};
@@ -470,6 +472,112 @@ extern "C" int mi355_lzss_batch_stage_times(const mi355_lzss_batch *b, const cha
     return k;
 }
 
+// ---- allocation-free Write ---------------------------------------------------------------------------------
+// mi355_lzss_write_noalloc: the kernels of mi355_lzss_write on a workspace that lives in a file-scope device array
+// instead of hipMalloc'ed buffers, inputs and outputs in the caller's device memory, everything enqueued on the
+// caller's stream - for callers that cannot allocate (HIP graph capture, serving loops).  Every GPU the library runs on
+// holds one copy of the array until the process ends; all calls on a GPU share it, so calls that overlap on one GPU race.
+constexpr uint32_t NOALLOC_MAX_N = MI355_LZSS_NOALLOC_MAX_INPUT;
+constexpr uint64_t NOALLOC_ELEMS = seg_stride(NOALLOC_MAX_N);
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)NOALLOC_ELEMS * 40 + (64u << 10);  // ~37 B per position + summaries (checked in noalloc_bind)
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+// The array's name is a host-side stand-in, not a device address: the address on each device comes from
+// hipGetSymbolAddress with that device current, once per device, and only that pointer is ever used.
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::mutex g_na_mu;
+static unsigned char *g_na_ptr[NOALLOC_MAX_DEVICES] = {};
+
+static int noalloc_scratch_ptr(int device, unsigned char **out) {  // the caller has made `device` current
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return fail(MI355_LZSS_E_DEVICE, "device %d beyond the scratch table", device);
+    std::lock_guard<std::mutex> lk(g_na_mu);
+    if (!g_na_ptr[device]) {
+        unsigned char *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(MI355_LZSS_E_DEVICE, "hipGetSymbolAddress returned a null scratch address");
+        g_na_ptr[device] = ptr;
+    }
+    *out = g_na_ptr[device];
+    return 0;
+}
+
+// lays the arrays of a one-blob batch of up to NOALLOC_MAX_N bytes out inside [base, base + NOALLOC_SCRATCH_BYTES)
+static int noalloc_bind(mi355_lzss_ctx *ctx) {
+    unsigned char *base = nullptr;
+    int rc;
+    if ((rc = noalloc_scratch_ptr(ctx->device, &base)) != 0) return rc;
+    mi355_lzss_batch *b = new mi355_lzss_batch();
+    b->ctx = ctx;
+    size_t used = 0;
+    auto take = [&](DevBuf &d, size_t bytes) {
+        d.p = base + used;
+        d.bytes = bytes;
+        used += (bytes + 255) & ~(size_t)255;
+    };
+    const uint64_t e = NOALLOC_ELEMS, e64 = e / 64 + 1, e256 = e / 256 + 1;
+    const uint64_t nch = (NOALLOC_MAX_N + LZSS_SHORT_WINDOW - 1) / LZSS_SHORT_WINDOW;
+    take(b->text, e); take(b->sortA, e * 8); take(b->sortB, e * 8); take(b->rlen, e);
+    take(b->sa, e * 4); take(b->isa, e * 4); take(b->lcp, e * 2); take(b->res, e * 4);
+    take(b->adv, e); take(b->kind, e); take(b->exitoff, e); take(b->tbits, e * 2);
+    take(b->b1, e64 * 2); take(b->b2, e64 * 2);
+    for (DevBuf *d : {&b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2}) take(*d, e64 * 4);
+    take(b->cdir, e64 * nch * 2);
+    take(b->entry, e256 * 2); take(b->tilebit, e256 * 8);
+    take(b->segs, sizeof(Seg)); take(b->nbits, 8); take(b->out_off, 16); take(b->out_len, 4); take(b->status, 4);
+    b->cap_elems = e;
+    b->max_blobs = 1;
+    if (used > NOALLOC_SCRATCH_BYTES) {
+        delete b;
+        return fail(MI355_LZSS_E_DEVICE, "scratch layout needs %zu bytes, the array has %zu", used, (size_t)NOALLOC_SCRATCH_BYTES);
+    }
+    ctx->na = b;
+    return 0;
+}
+
+namespace lzss {
+__global__ void noalloc_seg_kernel(Seg *s, uint32_t n, uint32_t start) { s[0] = Seg{0, n, start}; }
+}
+
+extern "C" int mi355_lzss_write_noalloc(mi355_lzss_ctx *ctx, const uint8_t *d_inbuf, size_t n, size_t start, unsigned bit_off,
+                                        uint8_t *d_out, size_t out_cap, uint64_t *d_nbits, int32_t *d_status, void *stream) {
+    if (!ctx || !ctx->na || (n && !d_inbuf) || !d_out || !d_nbits || !d_status) return fail(MI355_LZSS_E_ARG, "null argument");
+    if (n > NOALLOC_MAX_N)
+        return fail(MI355_LZSS_E_INPUT_SIZE, "input size must be <= %u for the allocation-free entry point", NOALLOC_MAX_N);
+    if (start > n) return fail(MI355_LZSS_E_ARG, "start beyond the end of the buffer");
+    if (bit_off > 7) return fail(MI355_LZSS_E_ARG, "bit_off must be 0..7");
+    if (out_cap == 0) return fail(MI355_LZSS_E_CAPACITY, "the output buffer needs at least one byte");
+    int rc;
+    if ((rc = set_device(ctx)) != 0) return rc;
+    mi355_lzss_batch *b = ctx->na;
+    hipStream_t sm = (hipStream_t)stream;
+    const uint64_t stride = seg_stride(n);
+    // the blob's text with its zero padding; everything else of the last call's contents is rewritten before it is read
+    if (n) HIP_TRY(hipMemcpyAsync(b->text.p, d_inbuf, n, hipMemcpyDeviceToDevice, sm));
+    HIP_TRY(hipMemsetAsync((uint8_t *)b->text.p + n, 0, (size_t)(stride - n), sm));
+    hipLaunchKernelGGL(noalloc_seg_kernel, dim3(1), dim3(1), 0, sm, b->segs.as<Seg>(), (uint32_t)n, (uint32_t)start);
+    b->n_blobs = 1;
+    b->max_n = (uint32_t)n;
+    const Seg *d_segs = b->segs.as<Seg>();
+    launch_sa_build(d_segs, 1, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
+    launch_lcp(d_segs, 1, b->max_n, batch_index(b), sm);
+    launch_window_index(d_segs, 1, b->max_n, batch_index(b), sm);
+    launch_match_head(d_segs, 1, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), sm);
+    launch_match(d_segs, 1, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), true, sm);
+    WalkWork ww = walk_work(b);
+    launch_decide(d_segs, 1, b->max_n, b->text.as<uint8_t>(), b->rlen.as<uint8_t>(), b->res.as<uint32_t>(), ww, sm);
+    launch_walk(d_segs, 1, ww, 0, bit_off, sm);
+    launch_out_offsets(1, ww, sm);
+    // emit ORs the bytes that tiles share into a zeroed output; worst case 37 bits per position
+    const size_t worst = (size_t)((bit_off + (uint64_t)LZSS_DYN_BITS * (n - start) + 7) / 8);
+    HIP_TRY(hipMemsetAsync(d_out, 0, std::max<size_t>(1, std::min(out_cap, worst)), sm));
+    launch_emit(d_segs, 1, b->max_n, b->text.as<uint8_t>(), b->res.as<uint32_t>(), batch_index(b), ctx->view, ww, 0, bit_off,
+                (uint32_t)ctx->dict.size(), ctx->res_idx[0], ctx->res_idx[1], d_out, out_cap, b->status.as<int32_t>(), sm);
+    HIP_TRY(hipMemcpyAsync(d_nbits, ww.nbits, 8, hipMemcpyDeviceToDevice, sm));
+    HIP_TRY(hipMemcpyAsync(d_status, b->status.p, 4, hipMemcpyDeviceToDevice, sm));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- context ----------------------------------------------------------------------------------------
 extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int device, mi355_lzss_ctx **out) {
     if (!out || (dict_len && !dict)) return fail(MI355_LZSS_E_ARG, "null argument");
@@ -561,6 +669,7 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     ctx->view.bmin2 = ctx->d_b2.as<uint16_t>();
     ctx->view.key = ctx->d_key.as<uint64_t>();
     ctx->view.bkt = ctx->d_bkt.as<int2>();
+    if ((rc = noalloc_bind(ctx)) != 0) return bail(rc);
     *out = ctx;
     return 0;
 }
@@ -575,6 +684,7 @@ extern "C" void mi355_lzss_ctx_destroy(mi355_lzss_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->scratch) mi355_lzss_batch_destroy(ctx->scratch);
+    delete ctx->na;  // its buffers are views of the static scratch array: nothing to free
     DevBuf *bufs[] = {&ctx->d_text, &ctx->d_sa, &ctx->d_isa, &ctx->d_lcp, &ctx->d_b1, &ctx->d_b2, &ctx->d_key, &ctx->d_bkt};
     for (DevBuf *d : bufs) d->release();
     for (int k = 0; k < mi355_lzss_ctx::kMaxSplit; ++k) {

@@ -26,7 +26,7 @@ constexpr uint32_t SEG_PAD = 64;      // stride = align(n + SEG_PAD)
 #ifndef LZSS_HEAD
 #define LZSS_HEAD 256
 #endif
-__host__ __device__ inline uint64_t seg_stride(uint64_t n) { return (n + SEG_PAD + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN; }
+__host__ __device__ constexpr inline uint64_t seg_stride(uint64_t n) { return (n + SEG_PAD + SEG_ALIGN - 1) / SEG_ALIGN * SEG_ALIGN; }
 constexpr int HEAD = LZSS_HEAD;         // positions below HEAD are matched by brute force (match_head_kernel)
 
 // packed per-position result of bestBackref (compress.go:146-173)

@@ -70,6 +70,21 @@ int mi355_lzss_best_backrefs(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, si
 int mi355_lzss_write(mi355_lzss_ctx *ctx, const uint8_t *inbuf, size_t n, size_t start,
                      unsigned bit_off, uint8_t *out, size_t out_cap, uint64_t *nbits);
 
+/* The same Write for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  It calls no hipMalloc /
+ * hipFree / allocating routine and does not synchronise: the kernels of mi355_lzss_write are enqueued on
+ * `stream` (a hipStream_t; NULL = the default stream) with their ~37 bytes per position of workspace in a
+ * static device array of the library (5.3 MB held by every GPU the library runs on until the process
+ * ends).  d_inbuf, d_out, d_nbits, d_status are DEVICE pointers: inbuf[0:n) in, the packed bits in
+ * d_out (zero padded, layout as above), *d_nbits = phrase bits, *d_status = 0 or MI355_LZSS_E_CAPACITY
+ * (then d_out holds nothing useful); all valid once the stream has reached the end of the call's work.
+ * Limit: n <= MI355_LZSS_NOALLOC_MAX_INPUT, larger inputs are rejected with MI355_LZSS_E_INPUT_SIZE.
+ * All calls on one GPU share that GPU's array (whatever the ctx): calls that overlap on one GPU race. */
+#define MI355_LZSS_NOALLOC_MAX_INPUT 131072u
+int mi355_lzss_write_noalloc(mi355_lzss_ctx *ctx, const uint8_t *d_inbuf, size_t n, size_t start,
+                             unsigned bit_off, uint8_t *d_out, size_t out_cap, uint64_t *d_nbits,
+                             int32_t *d_status, void *stream);
+
 /* CompressedSize256k (lzss/compress.go:384-407): 3 + ceil(bits/8) of write(d, 0); n <= 256 KiB */
 int mi355_lzss_compressed_size(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, uint64_t *size);
 

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch ships its own HIP runtime: when a test wants torch device buffers next to libmi355_lzss.so (tests/test_zz_no_alloc.py),
+# torch must have loaded first or it finds "no HIP GPUs" in a process whose runtime the library already started - the
+# same order as bench.py
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 for p in (HERE, ROOT):
