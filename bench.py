@@ -5,7 +5,8 @@ A step = one pass of the hot path (suffix-array index build, per-position back-r
 walk, bit emission) over one batch of synthetic 128 KiB calldata-like blobs that share a 64 KiB
 dictionary.  The 10 000-blob batch of config 3 is sharded blob b -> GPU b mod 8, i.e. 1250 blobs per
 GPU; every rank keeps that per-GPU shard size whatever N is (weak scaling, no collective on the data
-path).  Inputs are resident in HBM before the timed region; outputs stay in HBM.
+path).  `value`: inputs are resident in HBM before the timed region, outputs stay in HBM.  `transfer_inclusive`: the
+same blobs from pinned host buffers through the library's chunk pipeline, host to host.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--blobs B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -22,15 +23,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-PMC_FILE = "r01_f_pmc_hbm_traffic.csv"
+def _pmc_file():
+    """the newest committed PMC summary (profiles/rNN_x_pmc_hbm_traffic.csv, named per round)"""
+    d = os.path.join(ROOT, "profiles")
+    names = sorted(f for f in os.listdir(d) if f.endswith("_pmc_hbm_traffic.csv")) if os.path.isdir(d) else []
+    return names[-1] if names else None
+
+
+PMC_FILE = _pmc_file()
 
 
 def pmc_traffic(stage, n_blobs):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs of this same command with --overlap 1, KB -> bytes).  FETCH_SIZE is left
-    uncorrected: the guide's x2 applies to wide coalesced streams only and these kernels mix 2/4/8/16-byte
-    accesses.  The number of batch launches in the profiled run is the dispatch count of match_kernel (the
-    dictionary's one-segment launches at context creation add < 0.1 % to the other kernels' sums)."""
+    """HBM bytes per launch of the stage's kernel from the COMMITTED rocprofv3 --pmc passes of this same command
+    (scripts/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate runs with --overlap 1, KB -> bytes) - a
+    profile of the committed kernels, not a measurement of the run that prints it (PMC passes cannot run inside
+    the bench).  FETCH_SIZE is left uncorrected: the guide's x2 applies to wide coalesced streams; the factors for
+    this path's access widths were measured with scripts/calib_fetch.sh (profiles/*_fetch_calibration.txt).  The
+    number of batch launches in the profiled run is the dispatch count of match_kernel (the dictionary's
+    one-segment launches at context creation add < 0.1 % to the other kernels' sums)."""
+    if PMC_FILE is None:
+        return None, None
     path = os.path.join(ROOT, "profiles", PMC_FILE)
     kernel = {"sa_build": "lzss::sa_build_kernel", "match": "lzss::match_kernel", "lcp": "lzss::lcp_kernel"}.get(stage)
     if kernel is None or not os.path.exists(path) or n_blobs != 1250:
@@ -43,7 +55,8 @@ def pmc_traffic(stage, n_blobs):
             total += float(v) * 1024.0
         if k == "lzss::match_kernel" and c == "FETCH_SIZE":
             launches = max(1, int(nd))
-    return int(total / launches), "profiles/%s (rocprofv3 --pmc, FETCH_SIZE + WRITE_SIZE, per launch)" % PMC_FILE
+    return int(total / launches), ("committed profile profiles/%s (rocprofv3 --pmc, FETCH_SIZE + WRITE_SIZE, per launch; "
+                                   "not measured in this run)" % PMC_FILE)
 
 
 def main():
@@ -58,6 +71,9 @@ def main():
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming (config 4) sample")
     ap.add_argument("--overlap", type=int, default=2, help="concurrent sub-batches of the index / match stages")
     ap.add_argument("--stage-steps", type=int, default=2, help="extra untimed steps (one part) for the per-kernel times")
+    ap.add_argument("--pipe-repeats", type=int, default=4, help="the batch repeated this many times through the "
+                    "host-buffer pipeline (transfer-inclusive figure); 0 = skip")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's parallel leg (0 = min(16, cores))")
     args = ap.parse_args()
 
     import torch
@@ -135,6 +151,53 @@ def main():
     back = bt.download_decompressed()
     dec_ok = back == blobs
 
+    # ---- transfer-inclusive: the same blobs from pinned HOST buffers through mi355_lzss_compress_batch, which pipelines
+    #      chunks of 1250 blobs (upload of chunk k+1 and download of chunk k-1 overlap the kernels of chunk k); timed
+    #      around the whole call, outputs land in the caller's CSR layout on the host
+    pipe = None
+    if args.pipe_repeats > 0:
+        import ctypes as C
+        import numpy as np
+        from compress_amd import _lib
+        reps = args.pipe_repeats
+        nb = len(blobs) * reps
+        flat_one = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+        pin_in = compress_amd.PinnedBuffer(flat_one.size * reps)
+        for r_ in range(reps):
+            pin_in.array[r_ * flat_one.size:(r_ + 1) * flat_one.size] = flat_one
+        lens = np.array([len(b) for b in blobs] * reps, dtype=np.uint64)
+        in_off = np.zeros(nb + 1, dtype=np.uint64)
+        np.cumsum(lens, out=in_off[1:])
+        caps = np.array([(int(x) + 15) // 16 * 16 + 16 for x in out_len] * reps, dtype=np.uint64)  # the known sizes + slack
+        out_off = np.zeros(nb + 1, dtype=np.uint64)
+        np.cumsum(caps, out=out_off[1:])
+        pin_out = compress_amd.PinnedBuffer(int(out_off[-1]))
+        p_len = np.zeros(nb, dtype=np.uint32)
+        p_st = np.zeros(nb, dtype=np.int32)
+        ctx.set_chunk_bytes(in_bytes)
+
+        def run_pipe():
+            rc = _lib.lib().mi355_lzss_compress_batch(ctx.h, pin_in.ptr, in_off.ctypes.data_as(C.c_void_p), nb, pin_out.ptr,
+                                                      out_off.ctypes.data_as(C.c_void_p), p_len.ctypes.data_as(C.c_void_p),
+                                                      p_st.ctypes.data_as(C.c_void_p))
+            if rc != 0 or p_st.any():
+                raise SystemExit("pipelined batch failed: " + _lib.last_error())
+        run_pipe()                          # warm-up: allocates the two pipeline workspaces
+        barrier()
+        t0 = time.perf_counter()
+        run_pipe()
+        barrier()
+        t_pipe = shard.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        same = all(pin_out.array[int(out_off[k]):int(out_off[k]) + int(p_len[k])].tobytes() == outs[k % len(blobs)]
+                   for k in range(0, nb, max(1, nb // 97)))
+        pipe = {"value": round(in_bytes * reps * world / t_pipe / 1e6, 2), "unit": "MB/s", "blobs_per_gpu": nb,
+                "chunk_blobs": len(blobs), "seconds": round(t_pipe, 4), "host_buffers": "pinned (mi355_lzss_host_alloc)",
+                "equal_to_resident_outputs_on_sample": bool(same),
+                "note": "whole call: H2D + kernels + D2H + scatter into the caller's CSR layout; the batch is the step's "
+                        "blobs repeated %d times" % reps}
+        pin_in.close()
+        pin_out.close()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = in_bytes * world * args.steps / elapsed / 1e6
@@ -162,8 +225,23 @@ def main():
             "decompress": {"value": round(in_bytes * world * args.steps / dec_elapsed / 1e6, 2), "unit": "MB/s (decompressed bytes)",
                            "kernel_ms": round(dec_ms / args.steps, 3), "roundtrip_equal": dec_ok,
                            "achieved_GBps": round((in_bytes + int(out_total)) / (dec_ms / args.steps * 1e-3) / 1e9, 3)},
-            "pcie_inclusive_MBps": round(in_bytes / (t_up + elapsed / args.steps + t_down) / 1e6, 2),
+            "kernel_only_MBps": round(value, 2),
+            "transfer_inclusive": pipe,
+            "transfer_inclusive_frac_of_resident": round(pipe["value"] / value, 3) if pipe else None,
+            "serial_upload_compress_download_MBps": round(in_bytes / (t_up + elapsed / args.steps + t_down) / 1e6, 2),
         }
+        # ---- config 2: latency of ONE 128 KiB blob with the 64 KiB dictionary through Compress (host buffers in and out)
+        if world == 1:
+            comp1 = compress_amd.Compressor(dict_, device=local_rank)
+            comp1.Compress(blobs[0])
+            lat = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                o1 = comp1.Compress(blobs[0])
+                lat.append(time.perf_counter() - t0)
+            line["single_blob_latency_ms"] = {"workload": "config2: synthetic blob #0 (131072 B), 64 KiB dictionary, Compress()",
+                                              "median": round(sorted(lat)[len(lat) // 2] * 1e3, 3), "min": round(min(lat) * 1e3, 3),
+                                              "equal_to_batch_output": o1 == outs[0]}
         # ---- config 4 (streaming): the Write / Revert loop vs the speculative packer on a sample
         if world == 1 and not args.no_stream:
             from compress_amd import stream as S
@@ -184,19 +262,49 @@ def main():
         if not args.no_cpu and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
+            import threading
             oc = O.Compressor(dict_)
             done = 0
             t0 = time.perf_counter()
             exact = True
-            while done < len(blobs) and time.perf_counter() - t0 < args.cpu_seconds:
+            while done < len(blobs) and time.perf_counter() - t0 < args.cpu_seconds / 2:
                 ref = oc.compress(blobs[done])
                 exact = exact and (ref == outs[done])
                 done += 1
             cpu_t = time.perf_counter() - t0
-            line["cpu_baseline"] = {"value": round(done * args.blob_size / cpu_t / 1e6, 3), "unit": "MB/s", "cores": 1,
-                                    "kind": "port", "sample": f"first {done} blobs of the same batch, one-shot Compress, "
-                                                              "C restatement of the reference algorithm, 1 thread"}
-            line["bit_exact_vs_oracle"] = {"blobs_checked": done, "all_equal": exact}
+            one = done * args.blob_size / cpu_t / 1e6
+            # the parallel leg: one blob per thread at a time, one oracle compressor per thread (ctypes drops the GIL)
+            nthr = args.cpu_threads or min(16, os.cpu_count() or 1)
+            counts = [0] * nthr
+            flags = [True] * nthr
+            t_end = time.perf_counter() + args.cpu_seconds / 2
+            nxt = [done]
+            lock = threading.Lock()
+
+            def work(t):
+                c = O.Compressor(dict_)
+                while time.perf_counter() < t_end:
+                    with lock:
+                        k = nxt[0]
+                        nxt[0] += 1
+                    if k >= len(blobs):
+                        break
+                    flags[t] = flags[t] and (c.compress(blobs[k]) == outs[k])
+                    counts[t] += 1
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=work, args=(t,)) for t in range(nthr)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            par_t = time.perf_counter() - t0
+            par_done = sum(counts)
+            line["cpu_baseline"] = {"value": round(par_done * args.blob_size / par_t / 1e6, 3), "unit": "MB/s", "cores": nthr,
+                                    "kind": "port", "value_1thread": round(one, 3),
+                                    "sample": f"blobs of the same batch, one-shot Compress, C restatement of the reference "
+                                              f"algorithm: {done} blobs on 1 thread, then {par_done} blobs on {nthr} threads "
+                                              f"(one blob per thread at a time; host has {os.cpu_count()} logical CPUs)"}
+            line["bit_exact_vs_oracle"] = {"blobs_checked": done + par_done, "all_equal": bool(exact and all(flags))}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

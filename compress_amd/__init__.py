@@ -7,6 +7,6 @@ library and a GPU every data-path call raises.
 from .lzss import (  # noqa: F401
     MaxInputSize, MaxDictSize, SymbolDynamic, SymbolShort, Version, HeaderSize,
     Compressor, NewCompressor, AugmentDict, Decompress, Header, LzssError,
-    compress_batch, decompress_batch,
+    compress_batch, decompress_batch, compress_batch_multi, decompress_batch_multi, partition, PinnedBuffer,
 )
 from .info import CompressionPhrase, CompressedStreamInfo, ToCSV  # noqa: F401,E402

@@ -13,6 +13,14 @@ _vp, _sz, _u32, _u64, _i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c
 SIGNATURES = {
     "mi355_lzss_ctx_create": (_i32, [_vp, _sz, _i32, C.POINTER(_vp)]),
     "mi355_lzss_ctx_destroy": (None, [_vp]),
+    "mi355_lzss_ctx_create_decoder": (_i32, [_vp, _sz, _i32, C.POINTER(_vp)]),
+    "mi355_lzss_ctx_set_chunk_bytes": (_i32, [_vp, _u64]),
+    "mi355_lzss_host_alloc": (_vp, [_sz]),
+    "mi355_lzss_host_free": (None, [_vp]),
+    "mi355_lzss_compressed_size_batch": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp]),
+    "mi355_lzss_compress_batch_multi": (_i32, [_vp, _i32, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "mi355_lzss_decompress_batch_multi": (_i32, [_vp, _i32, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "mi355_lzss_partition": (_i32, [_vp, _u32, _i32, _vp]),
     "mi355_lzss_ctx_set_overlap": (_i32, [_vp, _i32]),
     "mi355_lzss_last_error": (C.c_char_p, []),
     "mi355_lzss_dict_info": (_i32, [_vp, C.POINTER(_u64), C.POINTER(C.c_int32 * 2)]),

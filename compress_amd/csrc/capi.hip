@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -34,7 +35,7 @@ static int fail(int code, const char *fmt, ...) {
 
 extern "C" const char *mi355_lzss_last_error(void) { return g_err; }
 
-// ---- device memory helpers ------------------------------------------------------------------------
+// ---- memory helpers ---------------------------------------------------------------------------------
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -77,31 +78,54 @@ struct PinBuf {
     T *as() const { return (T *)p; }
 };
 
+// pinned host memory for callers: transfers from / to such buffers are true DMA and overlap with the kernels
+extern "C" void *mi355_lzss_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)fail(MI355_LZSS_E_DEVICE, "hipHostMalloc of %zu bytes failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void mi355_lzss_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
 
 // ---- objects ----------------------------------------------------------------------------------------
 enum { ST_SA = 0, ST_LCP, ST_WINDEX, ST_MHEAD, ST_MATCH, ST_DECIDE, ST_WALK, ST_EMIT, ST_DECOMP, ST_COUNT };
 static const char *const kStageNames[ST_COUNT] = {"sa_build", "lcp", "window_index", "match_head", "match",
                                                   "decide", "walk", "emit", "decompress"};
 
+struct Pipeline;
+
 struct mi355_lzss_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool decode_only = false;   // ctx_create_decoder: the augmented dictionary's text only, no index
     std::vector<uint8_t> dict;  // augmented
     int32_t res_idx[2] = {0, 0};
     // dictionary index on the device
     DevBuf d_text, d_sa, d_isa, d_lcp, d_b1, d_b2, d_key, d_bkt;
     DictView view{};
-    mi355_lzss_batch *scratch = nullptr;  // for the single-buffer entry points
+    mi355_lzss_batch *scratch = nullptr;  // for the single-buffer entry points (created on first use)
     mi355_lzss_batch *na = nullptr;       // view of this device's static scratch array (mi355_lzss_write_noalloc)
     // side streams + events for running the index / match stages of sub-batches concurrently
     static constexpr int kMaxSplit = 4;
     hipStream_t side[kMaxSplit] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kMaxSplit] = {};
     int split = 2;
+    // workspaces of the entry points that may be called concurrently (compressed_size: compress.go:381-383)
+    std::mutex pool_mu;
+    std::vector<mi355_lzss_batch *> pool_free, pool_all;
+    // host-buffer batches: chunks of about this many input bytes in a copy / compute / copy pipeline
+    Pipeline *pipe = nullptr;
+    uint64_t chunk_bytes = 160ull << 20;
 };
 
 struct mi355_lzss_batch {
     mi355_lzss_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;  // the ctx's stream, or the batch's own (pool workspaces)
+    bool own_stream = false;
     uint32_t max_blobs = 0;
     uint64_t cap_elems = 0;  // element capacity of the per-position arrays
     // per-position arrays
@@ -110,18 +134,21 @@ struct mi355_lzss_batch {
     DevBuf cdir;                                        // per 64 ranks and chunk
     DevBuf tbits;                   // per position
     DevBuf entry, tilebit;          // per 256-tile
-    DevBuf segs, nbits, out_off, out_len, status;  // per blob
+    DevBuf segs, src_off, nbits, out_off, out_len, status;  // per blob
+    DevBuf flat;                                   // the blobs as the caller holds them (back to back), before layout
     DevBuf out;                                    // compressed bytes, blob b at out_off[b]
-    PinBuf h_stage;                                // pinned staging for uploads / downloads
+    PinBuf h_stage;                                // pinned staging for downloads
+    PinBuf h_meta;                                 // pinned: Seg[n] + source offsets[n] of the upload in flight
+    PinBuf h_res;                                  // pinned: out_off[n+1], nbits[n], out_len[n], status[n] of the last run
     std::vector<Seg> h_segs;
-    std::vector<uint64_t> h_out_off;
-    std::vector<uint32_t> h_out_len;
-    std::vector<uint64_t> h_nbits;
-    std::vector<int32_t> h_status, h_pre_status;
+    uint64_t *h_out_off = nullptr, *h_nbits = nullptr;  // views of h_res
+    uint32_t *h_out_len = nullptr;
+    int32_t *h_status = nullptr;
+    std::vector<int32_t> h_pre_status;
     uint32_t n_blobs = 0, max_n = 0;
-    uint64_t used_elems = 0;
+    uint64_t used_elems = 0, flat_bytes = 0;
     bool have_sizes = false;
-    uint32_t header_bytes = 0;
+    uint32_t header_bytes = 0, bit_off = 0;
     hipEvent_t ev[ST_COUNT + 1] = {};
     bool ev_valid[ST_COUNT + 1] = {};
     float stage_ms[ST_COUNT] = {};
@@ -157,6 +184,7 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
     if (max_blobs > b->max_blobs) {
         const size_t m = max_blobs;
         if ((rc = b->segs.ensure(m * sizeof(Seg))) != 0) return rc;
+        if ((rc = b->src_off.ensure(m * 8)) != 0) return rc;
         if ((rc = b->nbits.ensure(m * 8)) != 0) return rc;
         if ((rc = b->out_off.ensure((m + 1) * 8)) != 0) return rc;
         if ((rc = b->out_len.ensure(m * 4)) != 0) return rc;
@@ -205,17 +233,23 @@ static int mark(mi355_lzss_batch *b, int k) {
         HIP_TRY(hipEventCreate(&b->ev[k]));
         b->ev_valid[k] = true;
     }
-    HIP_TRY(hipEventRecord(b->ev[k], b->ctx->stream));
+    HIP_TRY(hipEventRecord(b->ev[k], b->stream));
     return 0;
 }
 
-extern "C" int mi355_lzss_batch_create(mi355_lzss_ctx *ctx, uint32_t max_blobs, uint64_t max_total_bytes,
-                                       mi355_lzss_batch **out) {
-    if (!ctx || !out) return fail(MI355_LZSS_E_ARG, "null argument");
+static int batch_new(mi355_lzss_ctx *ctx, uint32_t max_blobs, uint64_t max_total_bytes, bool own_stream, mi355_lzss_batch **out) {
     int rc;
     if ((rc = set_device(ctx)) != 0) return rc;
     mi355_lzss_batch *b = new mi355_lzss_batch();
     b->ctx = ctx;
+    b->stream = ctx->stream;
+    if (own_stream) {
+        if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete b;
+            return fail(MI355_LZSS_E_DEVICE, "hipStreamCreate failed");
+        }
+        b->own_stream = true;
+    }
     if (max_blobs == 0) max_blobs = 1;
     const uint64_t elems = max_total_bytes + (uint64_t)max_blobs * (SEG_PAD + SEG_ALIGN);
     if ((rc = batch_reserve(b, max_blobs, elems)) != 0) {
@@ -226,44 +260,94 @@ extern "C" int mi355_lzss_batch_create(mi355_lzss_ctx *ctx, uint32_t max_blobs, 
     return 0;
 }
 
+extern "C" int mi355_lzss_batch_create(mi355_lzss_ctx *ctx, uint32_t max_blobs, uint64_t max_total_bytes,
+                                       mi355_lzss_batch **out) {
+    if (!ctx || !out) return fail(MI355_LZSS_E_ARG, "null argument");
+    return batch_new(ctx, max_blobs, max_total_bytes, false, out);
+}
+
 extern "C" void mi355_lzss_batch_destroy(mi355_lzss_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     DevBuf *bufs[] = {&b->text, &b->sortA, &b->sortB, &b->rkA, &b->rkB, &b->flags, &b->rlen, &b->sa, &b->isa,
                       &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->cdir, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
-                      &b->tbits, &b->segs, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->out,
+                      &b->tbits, &b->segs, &b->src_off, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->flat, &b->out,
                       &b->d_cin, &b->d_cin_off, &b->d_dout, &b->d_dout_off, &b->d_dlen, &b->d_dstatus};
     for (DevBuf *d : bufs) d->release();
     b->h_stage.release();
+    b->h_meta.release();
+    b->h_res.release();
     for (int k = 0; k <= ST_COUNT; ++k)
         if (b->ev_valid[k]) (void)hipEventDestroy(b->ev[k]);
+    if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
 
-extern "C" int mi355_lzss_batch_upload(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
-                                       const uint32_t *starts) {
-    if (!b || !in_off || (n_blobs && !in)) return fail(MI355_LZSS_E_ARG, "null argument");
+// ---- upload: the caller's bytes go to the device as they are (one copy), a kernel lays them out ------------
+namespace lzss {
+// text[seg.off + x] = flat[src[blob] + x] for x < n, zero up to the segment's stride.  16 bytes per thread: the
+// source is read at any byte alignment (flat is readable 16 bytes past its end), the stores are aligned.
+__global__ __launch_bounds__(256) void layout_text_kernel(const Seg *segs, const uint64_t *src, const uint8_t *flat, uint8_t *text) {
+    const Seg sg = segs[blockIdx.y];
+    const uint64_t stride = seg_stride(sg.n);
+    const uint64_t x = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (x >= stride) return;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    typedef u32x4_t unaligned_t __attribute__((aligned(1)));
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (x < sg.n) {
+        v = *reinterpret_cast<const unaligned_t *>(flat + src[blockIdx.y] + x);
+        const uint64_t left = sg.n - x;  // bytes of the text in this piece
+        if (left < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t keep = (int64_t)left - 4 * q;  // bytes of word q that belong to the text
+                if (keep <= 0) v[q] = 0u;
+                else if (keep < 4) v[q] &= (1u << (8 * keep)) - 1u;
+            }
+        }
+    }
+    *reinterpret_cast<u32x4_t *>(text + sg.off + x) = v;
+}
+// the first min(*total, cap) bytes of out (16-byte granules) become zero
+__global__ __launch_bounds__(256) void zero_out_kernel(uint8_t *out, const uint64_t *total, uint64_t cap) {
+    const uint64_t t = *total < cap ? *total : cap;
+    const uint64_t words = (t + 15) / 16;
+    uint4 *o = reinterpret_cast<uint4 *>(out);
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < words; j += (uint64_t)gridDim.x * 256) o[j] = make_uint4(0, 0, 0, 0);
+}
+}  // namespace lzss
+
+// Enqueues on `s`: the blobs' bytes, their segment table, the layout kernel.  Host-side state of the batch is set
+// at once; the device side is ready when `s` has drained.  limit: blobs longer than this get E_INPUT_SIZE.
+static int upload_async(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
+                        const uint32_t *starts, uint64_t limit, hipStream_t s) {
     int rc;
-    if ((rc = set_device(b->ctx)) != 0) return rc;
     uint64_t elems = 0;
     uint32_t max_n = 0;
     b->h_segs.assign(n_blobs, Seg{});
     b->h_pre_status.assign(n_blobs, 0);
+    if ((rc = b->h_meta.ensure((size_t)std::max<uint32_t>(n_blobs, 1) * (sizeof(Seg) + 8))) != 0) return rc;
+    Seg *hs = b->h_meta.as<Seg>();
+    uint64_t *hsrc = reinterpret_cast<uint64_t *>(hs + n_blobs);
+    const uint64_t base = n_blobs ? in_off[0] : 0;
     for (uint32_t k = 0; k < n_blobs; ++k) {
         if (in_off[k + 1] < in_off[k]) return fail(MI355_LZSS_E_ARG, "in_off must be non-decreasing");
         uint64_t n = in_off[k + 1] - in_off[k];
-        if (n > LZSS_MAX_INPUT_SIZE) {  // compress.go:473-475
+        if (n > limit) {  // compress.go:473-475 (compress.go:390 for CompressedSize256k)
             b->h_pre_status[k] = MI355_LZSS_E_INPUT_SIZE;
             n = 0;
         }
         uint32_t st = starts ? starts[k] : 0;
         if (st > n) st = (uint32_t)n;
-        b->h_segs[k] = Seg{elems, (uint32_t)n, st};
+        b->h_segs[k] = hs[k] = Seg{elems, (uint32_t)n, st};
+        hsrc[k] = in_off[k] - base;
         elems += seg_stride(n);
         max_n = std::max<uint32_t>(max_n, (uint32_t)n);
     }
+    const uint64_t flat_bytes = n_blobs ? in_off[n_blobs] - base : 0;
     if ((rc = batch_reserve(b, std::max<uint32_t>(n_blobs, 1), std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
-    if ((rc = b->h_stage.ensure((size_t)std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
+    if ((rc = b->flat.ensure((size_t)flat_bytes + 16)) != 0) return rc;
     if (max_n + 1 > SA_BITMAP_MAX_N) {  // the fallback suffix sort keeps ranks and boundary flags in HBM
         const uint64_t e = b->cap_elems;
         if ((rc = b->rkA.ensure((size_t)(e * 4))) != 0 || (rc = b->rkB.ensure((size_t)(e * 4))) != 0 ||
@@ -274,31 +358,44 @@ extern "C" int mi355_lzss_batch_upload(mi355_lzss_batch *b, const uint8_t *in, c
         const uint64_t nch = std::max<uint32_t>(1, (max_n + LZSS_SHORT_WINDOW - 1) / LZSS_SHORT_WINDOW);
         if ((rc = b->cdir.ensure((size_t)((std::max<uint64_t>(elems, SEG_ALIGN) / 64 + 1) * nch * 2))) != 0) return rc;
     }
-    uint8_t *st = b->h_stage.as<uint8_t>();
-    for (uint32_t k = 0; k < n_blobs; ++k) {
-        const Seg &s = b->h_segs[k];
-        if (s.n) memcpy(st + s.off, in + in_off[k], s.n);
-        memset(st + s.off + s.n, 0, (size_t)(seg_stride(s.n) - s.n));
+    if (flat_bytes) HIP_TRY(hipMemcpyAsync(b->flat.p, in + base, (size_t)flat_bytes, hipMemcpyHostToDevice, s));
+    if (n_blobs) {
+        HIP_TRY(hipMemcpyAsync(b->segs.p, hs, n_blobs * sizeof(Seg), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->src_off.p, hsrc, n_blobs * 8, hipMemcpyHostToDevice, s));
+        const uint64_t stride = seg_stride(max_n);
+        dim3 g((uint32_t)((stride / 16 + 255) / 256), n_blobs);
+        hipLaunchKernelGGL(layout_text_kernel, g, dim3(256), 0, s, b->segs.as<Seg>(), b->src_off.as<uint64_t>(), b->flat.as<uint8_t>(),
+                           b->text.as<uint8_t>());
     }
-    hipStream_t sm = b->ctx->stream;
-    if (elems) HIP_TRY(hipMemcpyAsync(b->text.p, st, (size_t)elems, hipMemcpyHostToDevice, sm));
-    if (n_blobs) HIP_TRY(hipMemcpyAsync(b->segs.p, b->h_segs.data(), n_blobs * sizeof(Seg), hipMemcpyHostToDevice, sm));
-    HIP_TRY(hipStreamSynchronize(sm));
     b->n_blobs = n_blobs;
     b->max_n = max_n;
     b->used_elems = elems;
+    b->flat_bytes = flat_bytes;
     b->have_sizes = false;
+    return 0;
+}
+
+extern "C" int mi355_lzss_batch_upload(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
+                                       const uint32_t *starts) {
+    if (!b || !in_off || (n_blobs && !in)) return fail(MI355_LZSS_E_ARG, "null argument");
+    if (b->ctx->decode_only) return fail(MI355_LZSS_E_ARG, "the context was created for decompression only");
+    int rc;
+    if ((rc = set_device(b->ctx)) != 0) return rc;
+    if ((rc = upload_async(b, in, in_off, n_blobs, starts, LZSS_MAX_INPUT_SIZE, b->stream)) != 0) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // index build + match search for the uploaded blobs
 static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
     mi355_lzss_ctx *ctx = b->ctx;
-    hipStream_t sm = ctx->stream;
+    hipStream_t sm = b->stream;
     int rc;
     const Seg *d_segs = b->segs.as<Seg>();
     int split = ctx->split;
-    if (b->n_blobs < 8u * (uint32_t)split || b->max_n + 1 > SA_BITMAP_MAX_N) split = 1;
+    // the side streams belong to the ctx: only batches on the ctx's own stream (one at a time) may use them
+    if (b->n_blobs < 8u * (uint32_t)split || b->max_n + 1 > SA_BITMAP_MAX_N || sm != ctx->stream) split = 1;
     if (split == 1) {
         if ((rc = mark(b, ST_SA)) != 0) return rc;
         launch_sa_build(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
@@ -314,8 +411,8 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    // sub-batches on side streams: the tail of one sub-batch's suffix sort (a third wave of workgroups that fills
-    // less than half of the CUs) overlaps the next stages of another; per-stage events lose their meaning here
+    // sub-batches on side streams: the tail of one sub-batch's suffix sort (a last wave of workgroups that fills
+    // only part of the CUs) overlaps the next stages of another; per-stage events lose their meaning here
     if (!ctx->fork_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
     for (int k = 1; k < split; ++k) {
         if (!ctx->side[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
@@ -353,49 +450,83 @@ static int collect_stage_times(mi355_lzss_batch *b, int first, int last) {
     return 0;
 }
 
-// decide + walk (+ emit when emit != 0).  bit_off: first bit inside the first stream byte.
-static int run_walk_emit(mi355_lzss_batch *b, uint32_t header_bytes, uint32_t bit_off, bool emit) {
+static int enqueue_emit(mi355_lzss_batch *b) {
     mi355_lzss_ctx *ctx = b->ctx;
-    hipStream_t sm = ctx->stream;
+    WalkWork ww = walk_work(b);
+    // emit ORs the bytes that tiles share: the stream bytes must start out zero (their total is known on the device only)
+    hipLaunchKernelGGL(zero_out_kernel, dim3(512), dim3(256), 0, b->stream, b->out.as<uint8_t>(), ww.out_off + b->n_blobs, (uint64_t)b->out.bytes);
+    launch_emit(b->segs.as<Seg>(), b->n_blobs, b->max_n, b->text.as<uint8_t>(), b->res.as<uint32_t>(), batch_index(b), ctx->view, ww,
+                b->header_bytes, b->bit_off, (uint32_t)ctx->dict.size(), ctx->res_idx[0], ctx->res_idx[1], b->out.as<uint8_t>(),
+                b->out.bytes, b->status.as<int32_t>(), b->stream);
+    return 0;
+}
+
+// decide + walk (+ emit) and the read-back of the sizes, all enqueued on the batch's stream WITHOUT a host
+// synchronisation: the output buffer is sized from the input (ratio >= 0.8) and finish_walk_emit repairs the rare
+// batch that expands beyond it.  bit_off: first bit inside the first stream byte.
+static int enqueue_walk_emit(mi355_lzss_batch *b, uint32_t header_bytes, uint32_t bit_off, bool emit) {
+    hipStream_t sm = b->stream;
     int rc;
     const Seg *d_segs = b->segs.as<Seg>();
     WalkWork ww = walk_work(b);
+    b->header_bytes = header_bytes;
+    b->bit_off = bit_off;
     launch_decide(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), b->rlen.as<uint8_t>(), b->res.as<uint32_t>(), ww, sm);
     if ((rc = mark(b, ST_WALK)) != 0) return rc;
     launch_walk(d_segs, b->n_blobs, ww, header_bytes, bit_off, sm);
     launch_out_offsets(b->n_blobs, ww, sm);
     if ((rc = mark(b, ST_EMIT)) != 0) return rc;
-    b->h_out_off.assign(b->n_blobs + 1, 0);
-    b->h_out_len.assign(b->n_blobs, 0);
-    b->h_nbits.assign(b->n_blobs, 0);
-    b->h_status.assign(b->n_blobs, 0);
-    uint64_t total = 0;
+    const uint32_t nb = b->n_blobs;
+    if ((rc = b->h_res.ensure((size_t)(nb + 1) * 8 + (size_t)nb * 16 + 64)) != 0) return rc;
+    b->h_out_off = b->h_res.as<uint64_t>();
+    b->h_nbits = b->h_out_off + nb + 1;
+    b->h_out_len = reinterpret_cast<uint32_t *>(b->h_nbits + nb);
+    b->h_status = reinterpret_cast<int32_t *>(b->h_out_len + nb);
+    b->h_out_off[nb] = 0;
+    for (uint32_t k = 0; k < nb; ++k) b->h_status[k] = 0;
     if (emit) {
-        // the total size decides the capacity of the output buffer (8-byte read back, then emit)
-        HIP_TRY(hipMemcpyAsync(&total, ww.out_off + b->n_blobs, 8, hipMemcpyDeviceToHost, sm));
-        HIP_TRY(hipStreamSynchronize(sm));
-        if ((rc = b->out.ensure((size_t)std::max<uint64_t>(total, 16))) != 0) return rc;
-        HIP_TRY(hipMemsetAsync(b->out.p, 0, (size_t)std::max<uint64_t>(total, 16), sm));  // emit ORs the bytes tiles share
-        launch_emit(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), b->res.as<uint32_t>(), batch_index(b), ctx->view, ww, header_bytes, bit_off,
-                    (uint32_t)ctx->dict.size(), ctx->res_idx[0], ctx->res_idx[1], b->out.as<uint8_t>(), b->out.bytes,
-                    b->status.as<int32_t>(), sm);
+        const uint64_t guess = b->flat_bytes + b->flat_bytes / 4 + (uint64_t)nb * (16 + header_bytes) + 4096;
+        if ((rc = b->out.ensure((size_t)guess)) != 0) return rc;
+        if ((rc = enqueue_emit(b)) != 0) return rc;
     }
     if ((rc = mark(b, ST_EMIT + 1)) != 0) return rc;
-    if (b->n_blobs) {
-        HIP_TRY(hipMemcpyAsync(b->h_out_off.data(), ww.out_off, (b->n_blobs + 1) * 8, hipMemcpyDeviceToHost, sm));
-        HIP_TRY(hipMemcpyAsync(b->h_out_len.data(), ww.out_len, b->n_blobs * 4, hipMemcpyDeviceToHost, sm));
-        HIP_TRY(hipMemcpyAsync(b->h_nbits.data(), ww.nbits, b->n_blobs * 8, hipMemcpyDeviceToHost, sm));
-        if (emit) HIP_TRY(hipMemcpyAsync(b->h_status.data(), b->status.p, b->n_blobs * 4, hipMemcpyDeviceToHost, sm));
+    if (nb) {
+        HIP_TRY(hipMemcpyAsync(b->h_out_off, ww.out_off, (nb + 1) * 8, hipMemcpyDeviceToHost, sm));
+        HIP_TRY(hipMemcpyAsync(b->h_out_len, ww.out_len, nb * 4, hipMemcpyDeviceToHost, sm));
+        HIP_TRY(hipMemcpyAsync(b->h_nbits, ww.nbits, nb * 8, hipMemcpyDeviceToHost, sm));
+        if (emit) HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, nb * 4, hipMemcpyDeviceToHost, sm));
     }
-    HIP_TRY(hipStreamSynchronize(sm));
     HIP_TRY(hipGetLastError());
-    b->have_sizes = true;
-    b->header_bytes = header_bytes;
     return 0;
+}
+
+// after the stream has drained: the sizes are on the host; a batch that outgrew the output buffer is emitted again
+static int finish_walk_emit(mi355_lzss_batch *b, bool emit) {
+    int rc;
+    const uint32_t nb = b->n_blobs;
+    const uint64_t total = nb ? b->h_out_off[nb] : 0;
+    if (emit && total > b->out.bytes) {
+        if ((rc = b->out.ensure((size_t)total)) != 0) return rc;
+        if ((rc = enqueue_emit(b)) != 0) return rc;
+        HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, nb * 4, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(hipGetLastError());
+    }
+    b->have_sizes = true;
+    return 0;
+}
+
+static int run_walk_emit(mi355_lzss_batch *b, uint32_t header_bytes, uint32_t bit_off, bool emit) {
+    int rc;
+    if ((rc = enqueue_walk_emit(b, header_bytes, bit_off, emit)) != 0) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipGetLastError());
+    return finish_walk_emit(b, emit);
 }
 
 extern "C" int mi355_lzss_batch_compress(mi355_lzss_batch *b, int with_header) {
     if (!b) return fail(MI355_LZSS_E_ARG, "null argument");
+    if (b->ctx->decode_only) return fail(MI355_LZSS_E_ARG, "the context was created for decompression only");
     int rc;
     if ((rc = set_device(b->ctx)) != 0) return rc;
     if ((rc = run_index_and_match(b, true)) != 0) return rc;
@@ -415,6 +546,22 @@ extern "C" int mi355_lzss_batch_sizes(mi355_lzss_batch *b, uint32_t *out_len, ui
     return 0;
 }
 
+// the blobs of the last run from the pinned image `img` of the device output into the caller's layout
+static int scatter_outputs(mi355_lzss_batch *b, const uint8_t *img, uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
+                           int32_t *status) {
+    int worst = 0;
+    for (uint32_t k = 0; k < b->n_blobs; ++k) {  // also with nothing to copy: every blob gets its status
+        int32_t st = b->h_pre_status[k] ? b->h_pre_status[k] : b->h_status[k];
+        const uint64_t cap = out_off[k + 1] - out_off[k];
+        if (st == 0 && b->h_out_len[k] > cap) st = MI355_LZSS_E_CAPACITY;
+        if (st == 0 && b->h_out_len[k]) memcpy(out + out_off[k], img + b->h_out_off[k], b->h_out_len[k]);
+        if (out_len) out_len[k] = st == 0 ? b->h_out_len[k] : 0;  // a failed blob has no length
+        if (status) status[k] = st;
+        if (st && !worst) worst = st;
+    }
+    return worst;
+}
+
 extern "C" int mi355_lzss_batch_download(mi355_lzss_batch *b, uint8_t *out, const uint64_t *out_off, int32_t *status) {
     if (!b || !b->have_sizes || !out_off || (b->n_blobs && !out)) return fail(MI355_LZSS_E_ARG, "bad argument");
     int rc;
@@ -422,19 +569,10 @@ extern "C" int mi355_lzss_batch_download(mi355_lzss_batch *b, uint8_t *out, cons
     const uint64_t total = b->n_blobs ? b->h_out_off[b->n_blobs] : 0;
     if (total) {
         if ((rc = b->h_stage.ensure((size_t)total)) != 0) return rc;
-        hipStream_t sm = b->ctx->stream;
-        HIP_TRY(hipMemcpyAsync(b->h_stage.p, b->out.p, (size_t)total, hipMemcpyDeviceToHost, sm));
-        HIP_TRY(hipStreamSynchronize(sm));
+        HIP_TRY(hipMemcpyAsync(b->h_stage.p, b->out.p, (size_t)total, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
     }
-    int worst = 0;
-    for (uint32_t k = 0; k < b->n_blobs; ++k) {  // also with nothing to copy: every blob gets its status
-        int32_t st = b->h_pre_status[k] ? b->h_pre_status[k] : b->h_status[k];
-        const uint64_t cap = out_off[k + 1] - out_off[k];
-        if (st == 0 && b->h_out_len[k] > cap) st = MI355_LZSS_E_CAPACITY;
-        if (st == 0 && b->h_out_len[k]) memcpy(out + out_off[k], b->h_stage.as<uint8_t>() + b->h_out_off[k], b->h_out_len[k]);
-        if (status) status[k] = st;
-        if (st && !worst) worst = st;
-    }
+    const int worst = scatter_outputs(b, b->h_stage.as<uint8_t>(), out, out_off, nullptr, status);
     if (worst && !status) return fail(worst, "blob failed with status %d", worst);
     return 0;
 }
@@ -579,25 +717,32 @@ extern "C" int mi355_lzss_write_noalloc(mi355_lzss_ctx *ctx, const uint8_t *d_in
 }
 
 // ---- context ----------------------------------------------------------------------------------------
-extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int device, mi355_lzss_ctx **out) {
+static void augment_dict(const uint8_t *dict, size_t dict_len, std::vector<uint8_t> &aug) {  // lzss/compress.go:70-88
+    aug.assign(dict, dict + dict_len);
+    uint8_t found = 0;
+    bool both = false;
+    for (size_t i = 0; i < dict_len && !both; ++i) {
+        if (dict[i] == LZSS_SYMBOL_SHORT) found |= 2;
+        else if (dict[i] == LZSS_SYMBOL_DYNAMIC) found |= 4;
+        else continue;
+        both = (found == 6);
+    }
+    if (!both) {
+        aug.push_back(LZSS_SYMBOL_SHORT);
+        aug.push_back(LZSS_SYMBOL_DYNAMIC);
+    }
+}
+
+static int ensure_scratch(mi355_lzss_ctx *ctx) {
+    if (ctx->scratch) return 0;
+    return batch_new(ctx, 1, 0, false, &ctx->scratch);
+}
+
+static int ctx_create(const uint8_t *dict, size_t dict_len, int device, bool decode_only, mi355_lzss_ctx **out) {
     if (!out || (dict_len && !dict)) return fail(MI355_LZSS_E_ARG, "null argument");
     *out = nullptr;
-    // AugmentDict, lzss/compress.go:70-88
-    std::vector<uint8_t> aug(dict, dict + dict_len);
-    {
-        uint8_t found = 0;
-        bool both = false;
-        for (size_t i = 0; i < dict_len && !both; ++i) {
-            if (dict[i] == LZSS_SYMBOL_SHORT) found |= 2;
-            else if (dict[i] == LZSS_SYMBOL_DYNAMIC) found |= 4;
-            else continue;
-            both = (found == 6);
-        }
-        if (!both) {
-            aug.push_back(LZSS_SYMBOL_SHORT);
-            aug.push_back(LZSS_SYMBOL_DYNAMIC);
-        }
-    }
+    std::vector<uint8_t> aug;
+    augment_dict(dict, dict_len, aug);
     if (aug.size() > LZSS_MAX_DICT_SIZE)  // compress.go:39-41
         return fail(MI355_LZSS_E_DICT_SIZE, "dict size must be <= %d", LZSS_MAX_DICT_SIZE);
     int ndev = 0;
@@ -608,6 +753,7 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     mi355_lzss_ctx *ctx = new mi355_lzss_ctx();
     ctx->device = device;
     ctx->dict = aug;
+    ctx->decode_only = decode_only;
     // dictReservedIdx, compress.go:47-59: last occurrence of each symbol up to the point both were seen
     {
         bool fe = false, ff = false;
@@ -626,27 +772,38 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     if ((rc = set_device(ctx)) != 0) return bail(rc);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(MI355_LZSS_E_DEVICE, "hipStreamCreate failed"));
+    hipStream_t sm = ctx->stream;
+    const size_t stride = (size_t)seg_stride(aug.size());
+
+    if (decode_only) {  // Decompress (decompress.go:34) only augments the dictionary: text on the device, nothing else
+        if ((rc = ctx->d_text.ensure(stride)) != 0) return bail(rc);
+        if (hipMemsetAsync(ctx->d_text.p, 0, stride, sm) != hipSuccess ||
+            hipMemcpyAsync(ctx->d_text.p, aug.data(), aug.size(), hipMemcpyHostToDevice, sm) != hipSuccess ||
+            hipStreamSynchronize(sm) != hipSuccess)
+            return bail(fail(MI355_LZSS_E_DEVICE, "uploading the dictionary failed"));
+        ctx->view.T = ctx->d_text.as<uint8_t>();
+        ctx->view.n = (uint32_t)aug.size();
+        *out = ctx;
+        return 0;
+    }
 
     if (const char *e = getenv("MI355_LZSS_SPLIT")) {
         const int v = atoi(e);
         ctx->split = v < 1 ? 1 : (v > mi355_lzss_ctx::kMaxSplit ? mi355_lzss_ctx::kMaxSplit : v);
     }
     // dictionary index (compress.go:64) built with the same kernels as the input index
-    mi355_lzss_batch *b = nullptr;
-    if ((rc = mi355_lzss_batch_create(ctx, 1, aug.size(), &b)) != 0) return bail(rc);
-    ctx->scratch = b;
+    if ((rc = ensure_scratch(ctx)) != 0) return bail(rc);
+    mi355_lzss_batch *b = ctx->scratch;
     const uint64_t off2[2] = {0, aug.size()};
-    if ((rc = mi355_lzss_batch_upload(b, aug.data(), off2, 1, nullptr)) != 0) return bail(rc);
-    launch_sa_build(b->segs.as<Seg>(), 1, b->max_n, b->text.as<uint8_t>(), sa_work(b), ctx->stream);
-    launch_lcp(b->segs.as<Seg>(), 1, b->max_n, batch_index(b), ctx->stream);
-    const size_t stride = (size_t)seg_stride(aug.size());
+    if ((rc = upload_async(b, aug.data(), off2, 1, nullptr, LZSS_MAX_DICT_SIZE, sm)) != 0) return bail(rc);
+    launch_sa_build(b->segs.as<Seg>(), 1, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
+    launch_lcp(b->segs.as<Seg>(), 1, b->max_n, batch_index(b), sm);
     if ((rc = ctx->d_text.ensure(stride)) != 0) return bail(rc);
     if ((rc = ctx->d_sa.ensure(stride * 4)) != 0) return bail(rc);
     if ((rc = ctx->d_isa.ensure(stride * 4)) != 0) return bail(rc);
     if ((rc = ctx->d_lcp.ensure(stride * 2)) != 0) return bail(rc);
     if ((rc = ctx->d_b1.ensure((stride / 64 + 1) * 2)) != 0) return bail(rc);
     if ((rc = ctx->d_b2.ensure((stride / 64 + 1) * 2)) != 0) return bail(rc);
-    hipStream_t sm = ctx->stream;
 #define CP(dst, src, bytes)                                                                              \
     if (hipMemcpyAsync(ctx->dst.p, b->src.p, (bytes), hipMemcpyDeviceToDevice, sm) != hipSuccess)         \
         return bail(fail(MI355_LZSS_E_DEVICE, "device copy of the dictionary index failed"));
@@ -674,15 +831,32 @@ extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int d
     return 0;
 }
 
+extern "C" int mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int device, mi355_lzss_ctx **out) {
+    return ctx_create(dict, dict_len, device, false, out);
+}
+extern "C" int mi355_lzss_ctx_create_decoder(const uint8_t *dict, size_t dict_len, int device, mi355_lzss_ctx **out) {
+    return ctx_create(dict, dict_len, device, true, out);
+}
+
 extern "C" int mi355_lzss_ctx_set_overlap(mi355_lzss_ctx *ctx, int parts) {
     if (!ctx || parts < 1 || parts > mi355_lzss_ctx::kMaxSplit) return fail(MI355_LZSS_E_ARG, "overlap parts must be 1..%d", mi355_lzss_ctx::kMaxSplit);
     ctx->split = parts;
     return 0;
 }
 
+extern "C" int mi355_lzss_ctx_set_chunk_bytes(mi355_lzss_ctx *ctx, uint64_t bytes) {
+    if (!ctx || bytes == 0) return fail(MI355_LZSS_E_ARG, "chunk size must be positive");
+    ctx->chunk_bytes = bytes;
+    return 0;
+}
+
+static void pipeline_destroy(Pipeline *p);
+
 extern "C" void mi355_lzss_ctx_destroy(mi355_lzss_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    pipeline_destroy(ctx->pipe);
+    for (mi355_lzss_batch *b : ctx->pool_all) mi355_lzss_batch_destroy(b);
     if (ctx->scratch) mi355_lzss_batch_destroy(ctx->scratch);
     delete ctx->na;  // its buffers are views of the static scratch array: nothing to free
     DevBuf *bufs[] = {&ctx->d_text, &ctx->d_sa, &ctx->d_isa, &ctx->d_lcp, &ctx->d_b1, &ctx->d_b2, &ctx->d_key, &ctx->d_bkt};
@@ -707,23 +881,32 @@ extern "C" int mi355_lzss_dict_info(const mi355_lzss_ctx *ctx, uint64_t *aug_len
 }
 
 // ---- single-buffer entry points -----------------------------------------------------------------------
-static int upload_one(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, size_t start) {
-    if (!ctx || (n && !d)) return fail(MI355_LZSS_E_ARG, "null argument");
+static int upload_one(mi355_lzss_batch *b, const uint8_t *d, size_t n, size_t start) {
+    if (n && !d) return fail(MI355_LZSS_E_ARG, "null argument");
     if (n > LZSS_MAX_INPUT_SIZE) return fail(MI355_LZSS_E_INPUT_SIZE, "input size must be <= %d", LZSS_MAX_INPUT_SIZE);
     if (start > n) return fail(MI355_LZSS_E_ARG, "start beyond the end of the buffer");
     const uint64_t off2[2] = {0, n};
     const uint32_t st = (uint32_t)start;
-    return mi355_lzss_batch_upload(ctx->scratch, d ? d : (const uint8_t *)"", off2, 1, &st);
+    return upload_async(b, d ? d : (const uint8_t *)"", off2, 1, &st, LZSS_MAX_INPUT_SIZE, b->stream);
+}
+
+static int compress_ctx(mi355_lzss_ctx *ctx) {  // a ctx that can compress, made current, with its scratch batch
+    if (!ctx) return fail(MI355_LZSS_E_ARG, "null argument");
+    if (ctx->decode_only) return fail(MI355_LZSS_E_ARG, "the context was created for decompression only");
+    int rc;
+    if ((rc = set_device(ctx)) != 0) return rc;
+    return ensure_scratch(ctx);
 }
 
 extern "C" int mi355_lzss_best_backrefs(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, size_t start, int32_t *addr,
                                         int32_t *len, uint8_t *type) {
     int rc;
-    if ((rc = upload_one(ctx, d, n, start)) != 0) return rc;
+    if ((rc = compress_ctx(ctx)) != 0) return rc;
     mi355_lzss_batch *b = ctx->scratch;
+    if ((rc = upload_one(b, d, n, start)) != 0) return rc;
     if ((rc = run_index_and_match(b, false)) != 0) return rc;
     std::vector<uint32_t> packed(n ? n : 1);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
     if ((rc = mi355_lzss_batch_results(b, 0, packed.data(), n)) != 0) return rc;
     const int dict_len = (int)ctx->dict.size();
     for (size_t i = start; i < n; ++i) {
@@ -751,8 +934,9 @@ extern "C" int mi355_lzss_write(mi355_lzss_ctx *ctx, const uint8_t *inbuf, size_
                                 uint8_t *out, size_t out_cap, uint64_t *nbits) {
     if (bit_off > 7) return fail(MI355_LZSS_E_ARG, "bit_off must be 0..7");
     int rc;
-    if ((rc = upload_one(ctx, inbuf, n, start)) != 0) return rc;
+    if ((rc = compress_ctx(ctx)) != 0) return rc;
     mi355_lzss_batch *b = ctx->scratch;
+    if ((rc = upload_one(b, inbuf, n, start)) != 0) return rc;
     if ((rc = run_index_and_match(b, true)) != 0) return rc;
     if ((rc = run_walk_emit(b, 0, bit_off, true)) != 0) return rc;
     if (nbits) *nbits = b->h_nbits[0];
@@ -763,36 +947,223 @@ extern "C" int mi355_lzss_write(mi355_lzss_ctx *ctx, const uint8_t *inbuf, size_
     return 0;
 }
 
+// ---- CompressedSize256k: stateless and thread-safe (compress.go:381-383) -----------------------------------
+// Every call takes a workspace of its own (own stream, own buffers) from the ctx's pool, so calls from several
+// threads share nothing but the read-only dictionary index.
+static int pool_acquire(mi355_lzss_ctx *ctx, mi355_lzss_batch **out) {
+    {
+        std::lock_guard<std::mutex> lk(ctx->pool_mu);
+        if (!ctx->pool_free.empty()) {
+            *out = ctx->pool_free.back();
+            ctx->pool_free.pop_back();
+            return 0;
+        }
+    }
+    mi355_lzss_batch *b = nullptr;
+    int rc;
+    if ((rc = batch_new(ctx, 1, 0, true, &b)) != 0) return rc;
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    ctx->pool_all.push_back(b);
+    *out = b;
+    return 0;
+}
+static void pool_release(mi355_lzss_ctx *ctx, mi355_lzss_batch *b) {
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    ctx->pool_free.push_back(b);
+}
+
+extern "C" int mi355_lzss_compressed_size_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
+                                                uint64_t *sizes, int32_t *status) {
+    if (!ctx || !in_off || (n_blobs && !in) || !sizes) return fail(MI355_LZSS_E_ARG, "null argument");
+    if (ctx->decode_only) return fail(MI355_LZSS_E_ARG, "the context was created for decompression only");
+    int rc;
+    if ((rc = set_device(ctx)) != 0) return rc;
+    mi355_lzss_batch *b = nullptr;
+    if ((rc = pool_acquire(ctx, &b)) != 0) return rc;
+    auto run = [&]() -> int {
+        int r;
+        if ((r = upload_async(b, in, in_off, n_blobs, nullptr, LZSS_SIZE256K_MAX, b->stream)) != 0) return r;
+        if ((r = run_index_and_match(b, true)) != 0) return r;
+        if ((r = run_walk_emit(b, LZSS_HEADER_SIZE, 0, false)) != 0) return r;
+        int worst = 0;
+        for (uint32_t k = 0; k < n_blobs; ++k) {
+            const int32_t st = b->h_pre_status[k];
+            sizes[k] = st ? 0 : b->h_out_len[k];
+            if (status) status[k] = st;
+            if (st && !worst) worst = st;
+        }
+        if (worst && !status) return fail(worst, "input size must be <= %d", LZSS_SIZE256K_MAX);
+        return 0;
+    };
+    rc = run();
+    pool_release(ctx, b);
+    return rc;
+}
+
 extern "C" int mi355_lzss_compressed_size(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, uint64_t *size) {
     if (n > LZSS_SIZE256K_MAX) return fail(MI355_LZSS_E_INPUT_SIZE, "input size must be <= %d", LZSS_SIZE256K_MAX);
-    int rc;
-    if ((rc = upload_one(ctx, d, n, 0)) != 0) return rc;
-    mi355_lzss_batch *b = ctx->scratch;
-    if ((rc = run_index_and_match(b, true)) != 0) return rc;
-    if ((rc = run_walk_emit(b, LZSS_HEADER_SIZE, 0, false)) != 0) return rc;
-    if (size) *size = b->h_out_len[0];
+    if (n && !d) return fail(MI355_LZSS_E_ARG, "null argument");
+    const uint64_t off2[2] = {0, n};
+    uint64_t sz = 0;
+    const int rc = mi355_lzss_compressed_size_batch(ctx, d ? d : (const uint8_t *)"", off2, 1, &sz, nullptr);
+    if (rc == 0 && size) *size = sz;
+    return rc;
+}
+
+// ---- host-buffer batches: chunks in a copy-in / compute / copy-out pipeline ---------------------------------------
+// Chunk k's bytes go up on the copy-in stream while chunk k-1 computes and chunk k-2's streams come down: two
+// workspaces, three streams, no host synchronisation inside a chunk's kernel sequence.  The caller's buffers are used
+// as they are: pinned ones (mi355_lzss_host_alloc) make both copies true DMA.
+struct Pipeline {
+    mi355_lzss_batch *slot[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    PinBuf h_out[2];
+};
+
+static void pipeline_destroy(Pipeline *p) {
+    if (!p) return;
+    for (int k = 0; k < 2; ++k) {
+        if (p->slot[k]) mi355_lzss_batch_destroy(p->slot[k]);
+        if (p->ev_up[k]) (void)hipEventDestroy(p->ev_up[k]);
+        if (p->ev_done[k]) (void)hipEventDestroy(p->ev_done[k]);
+        p->h_out[k].release();
+    }
+    if (p->s_in) (void)hipStreamDestroy(p->s_in);
+    if (p->s_out) (void)hipStreamDestroy(p->s_out);
+    delete p;
+}
+
+static int pipeline_get(mi355_lzss_ctx *ctx, Pipeline **out) {
+    if (!ctx->pipe) {
+        Pipeline *p = new Pipeline();
+        ctx->pipe = p;  // owned by the ctx from here on (a partial one is destroyed with it)
+        HIP_TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            int rc;
+            if ((rc = batch_new(ctx, 1, 0, false, &p->slot[k])) != 0) return rc;
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_up[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_done[k], hipEventDisableTiming));
+        }
+    }
+    if (!ctx->pipe->slot[1] || !ctx->pipe->ev_done[1]) return fail(MI355_LZSS_E_DEVICE, "the transfer pipeline could not be set up");
+    *out = ctx->pipe;
     return 0;
 }
 
-// ---- host-buffer batch ----------------------------------------------------------------------------------
-extern "C" int mi355_lzss_compress_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
-                                         uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
-    if (!ctx || !in_off || !out_off) return fail(MI355_LZSS_E_ARG, "null argument");
+// consecutive blobs [first, last) whose bytes stay within `budget` (at least one blob)
+static uint32_t chunk_end(const uint64_t *off, uint32_t first, uint32_t n_blobs, uint64_t budget) {
+    uint32_t last = first + 1;
+    while (last < n_blobs && off[last + 1] - off[first] <= budget && last - first < (1u << 20)) ++last;
+    return last;
+}
+
+static int compress_pipelined(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs, uint8_t *out,
+                              const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
     int rc;
-    mi355_lzss_batch *b = ctx->scratch;
-    if ((rc = mi355_lzss_batch_upload(b, in, in_off, n_blobs, nullptr)) != 0) return rc;
-    if ((rc = mi355_lzss_batch_compress(b, 1)) != 0) return rc;
-    std::vector<int32_t> st(n_blobs ? n_blobs : 1, 0);
-    rc = mi355_lzss_batch_download(b, out, out_off, st.data());
-    int worst = 0;
-    for (uint32_t k = 0; k < n_blobs; ++k) {  // a failed blob has no length
-        if (out_len) out_len[k] = (rc == 0 && st[k] == 0) ? b->h_out_len[k] : 0;
-        if (status) status[k] = st[k];
-        if (st[k] && !worst) worst = st[k];
+    if ((rc = set_device(ctx)) != 0) return rc;
+    Pipeline *p = nullptr;
+    if ((rc = pipeline_get(ctx, &p)) != 0) return rc;
+    struct Chunk { uint32_t first, last; };
+    std::vector<Chunk> chunks;
+    for (uint32_t f = 0; f < n_blobs;) {
+        const uint32_t l = chunk_end(in_off, f, n_blobs, ctx->chunk_bytes);
+        chunks.push_back(Chunk{f, l});
+        f = l;
     }
-    if (rc != 0) return rc;
+    int worst = 0;
+    // chunk k's streams come down (and go to the caller's layout) while chunk k+1 computes
+    auto finish = [&](size_t k) -> int {
+        const int s = (int)(k & 1);
+        mi355_lzss_batch *b = p->slot[s];
+        const Chunk &c = chunks[k];
+        int r;
+        HIP_TRY(hipEventSynchronize(p->ev_done[s]));
+        if ((r = finish_walk_emit(b, true)) != 0) return r;
+        const uint64_t total = b->n_blobs ? b->h_out_off[b->n_blobs] : 0;
+        if (total) {
+            if ((r = p->h_out[s].ensure((size_t)total)) != 0) return r;
+            HIP_TRY(hipMemcpyAsync(p->h_out[s].p, b->out.p, (size_t)total, hipMemcpyDeviceToHost, p->s_out));
+            HIP_TRY(hipStreamSynchronize(p->s_out));
+        }
+        const int w = scatter_outputs(b, p->h_out[s].as<uint8_t>(), out, out_off + c.first, out_len ? out_len + c.first : nullptr,
+                                      status ? status + c.first : nullptr);
+        if (w && !worst) worst = w;
+        return 0;
+    };
+    for (size_t k = 0; k < chunks.size(); ++k) {
+        const int s = (int)(k & 1);
+        mi355_lzss_batch *b = p->slot[s];
+        const Chunk &c = chunks[k];
+        // slot s is free: chunk k-2 was finished (synchronised) in the previous iteration
+        if ((rc = upload_async(b, in, in_off + c.first, c.last - c.first, nullptr, LZSS_MAX_INPUT_SIZE, p->s_in)) != 0) return rc;
+        HIP_TRY(hipEventRecord(p->ev_up[s], p->s_in));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, p->ev_up[s], 0));
+        if ((rc = run_index_and_match(b, true)) != 0) return rc;
+        if ((rc = enqueue_walk_emit(b, LZSS_HEADER_SIZE, 0, true)) != 0) return rc;
+        HIP_TRY(hipEventRecord(p->ev_done[s], ctx->stream));
+        if (k >= 1 && (rc = finish(k - 1)) != 0) return rc;
+    }
+    if (!chunks.empty() && (rc = finish(chunks.size() - 1)) != 0) return rc;
     if (worst && !status) return fail(worst, "blob failed with status %d", worst);
     return 0;
+}
+
+extern "C" int mi355_lzss_compress_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
+                                         uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
+    if (!ctx || !in_off || !out_off || (n_blobs && (!in || !out))) return fail(MI355_LZSS_E_ARG, "null argument");
+    if (ctx->decode_only) return fail(MI355_LZSS_E_ARG, "the context was created for decompression only");
+    return compress_pipelined(ctx, in, in_off, n_blobs, out, out_off, out_len, status);
+}
+
+// ---- one call for several devices: contiguous blob ranges balanced by bytes, one host thread per context ----------
+extern "C" int mi355_lzss_partition(const uint64_t *off, uint32_t n_blobs, int n_parts, uint32_t *first) {
+    if (!off || !first || n_parts < 1) return fail(MI355_LZSS_E_ARG, "bad argument");
+    const uint64_t base = off[0], total = off[n_blobs] - base;
+    uint32_t b = 0;
+    first[0] = 0;
+    for (int t = 1; t < n_parts; ++t) {
+        // part t starts at the first blob whose start offset reaches t / n_parts of the bytes; never before part t-1
+        const uint64_t target = (uint64_t)((unsigned __int128)total * (unsigned)t / (unsigned)n_parts);
+        while (b < n_blobs && off[b] - base < target) ++b;
+        first[t] = b;
+    }
+    first[n_parts] = n_blobs;
+    return 0;
+}
+
+typedef int (*batch_fn)(mi355_lzss_ctx *, const uint8_t *, const uint64_t *, uint32_t, uint8_t *, const uint64_t *, uint32_t *, int32_t *);
+
+static int run_multi(batch_fn fn, mi355_lzss_ctx *const *ctxs, int n_ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
+                     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
+    if (!ctxs || n_ctx < 1 || !in_off || !out_off) return fail(MI355_LZSS_E_ARG, "null argument");
+    for (int t = 0; t < n_ctx; ++t)
+        if (!ctxs[t]) return fail(MI355_LZSS_E_ARG, "null context");
+    std::vector<uint32_t> first((size_t)n_ctx + 1);
+    int rc;
+    if ((rc = mi355_lzss_partition(in_off, n_blobs, n_ctx, first.data())) != 0) return rc;
+    std::vector<int> rcs((size_t)n_ctx, 0);
+    std::vector<std::string> errs((size_t)n_ctx);
+    auto work = [&](int t) {
+        const uint32_t f = first[(size_t)t], cnt = first[(size_t)t + 1] - f;
+        if (cnt == 0) return;
+        rcs[(size_t)t] = fn(ctxs[t], in, in_off + f, cnt, out, out_off + f, out_len ? out_len + f : nullptr, status ? status + f : nullptr);
+        if (rcs[(size_t)t] != 0) errs[(size_t)t] = g_err;  // the error text is per thread
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_ctx; ++t) th.emplace_back(work, t);
+    work(0);
+    for (std::thread &x : th) x.join();
+    for (int t = 0; t < n_ctx; ++t)
+        if (rcs[(size_t)t] != 0) return fail(rcs[(size_t)t], "context %d: %s", t, errs[(size_t)t].c_str());
+    return 0;
+}
+
+extern "C" int mi355_lzss_compress_batch_multi(mi355_lzss_ctx *const *ctxs, int n_ctx, const uint8_t *in, const uint64_t *in_off,
+                                               uint32_t n_blobs, uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
+                                               int32_t *status) {
+    return run_multi(mi355_lzss_compress_batch, ctxs, n_ctx, in, in_off, n_blobs, out, out_off, out_len, status);
 }
 
 // ---- decompression: see decompress.hip ----------------------------------------------------------------------
@@ -818,7 +1189,7 @@ extern "C" int mi355_lzss_batch_upload_compressed(mi355_lzss_batch *b, const uin
     if ((rc = b->d_dout_off.ensure((n_blobs + 1) * 8)) != 0) return rc;
     if ((rc = b->d_dlen.ensure(std::max<uint32_t>(n_blobs, 1) * 4)) != 0) return rc;
     if ((rc = b->d_dstatus.ensure(std::max<uint32_t>(n_blobs, 1) * 4)) != 0) return rc;
-    hipStream_t sm = b->ctx->stream;
+    hipStream_t sm = b->stream;
     HIP_TRY(hipMemsetAsync((uint8_t *)b->d_cin.p + cin, 0, 16, sm));
     if (cin) HIP_TRY(hipMemcpyAsync(b->d_cin.p, in + in_off[0], (size_t)cin, hipMemcpyHostToDevice, sm));
     HIP_TRY(hipMemcpyAsync(b->d_cin_off.p, b->h_cin_off.data(), (n_blobs + 1) * 8, hipMemcpyHostToDevice, sm));
@@ -836,13 +1207,16 @@ extern "C" int mi355_lzss_batch_decompress(mi355_lzss_batch *b) {
     if ((rc = mark(b, ST_DECOMP)) != 0) return rc;
     launch_decompress(b->d_cin.as<uint8_t>(), b->d_cin_off.as<uint64_t>(), b->n_dblobs, b->d_dout.as<uint8_t>(),
                       b->d_dout_off.as<uint64_t>(), ctx->view.T, ctx->view.n, b->d_dlen.as<uint32_t>(),
-                      b->d_dstatus.as<int32_t>(), ctx->stream);
+                      b->d_dstatus.as<int32_t>(), b->stream);
     if ((rc = mark(b, ST_DECOMP + 1)) != 0) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipGetLastError());
     return collect_stage_times(b, ST_DECOMP, ST_DECOMP + 1);
 }
 
+// The device output is laid out like the caller's (blob k at out_off[k] - out_off[0], capacity up to out_off[k+1]),
+// so when the capacities are mostly used ONE copy moves everything straight into the caller's buffer (the bytes of
+// a blob's region beyond out_len[k] are unspecified then); sparse layouts are copied blob by blob.
 extern "C" int mi355_lzss_batch_download_decompressed(mi355_lzss_batch *b, uint8_t *out, const uint64_t *out_off,
                                                       uint32_t *out_len, int32_t *status) {
     if (!b || !out_off || (b->n_dblobs && !out)) return fail(MI355_LZSS_E_ARG, "null argument");
@@ -852,25 +1226,32 @@ extern "C" int mi355_lzss_batch_download_decompressed(mi355_lzss_batch *b, uint8
     if (nb == 0) return 0;
     std::vector<uint32_t> lens(nb);
     std::vector<int32_t> sts(nb);
-    hipStream_t sm = b->ctx->stream;
+    hipStream_t sm = b->stream;
     HIP_TRY(hipMemcpyAsync(lens.data(), b->d_dlen.p, nb * 4, hipMemcpyDeviceToHost, sm));
     HIP_TRY(hipMemcpyAsync(sts.data(), b->d_dstatus.p, nb * 4, hipMemcpyDeviceToHost, sm));
     HIP_TRY(hipStreamSynchronize(sm));
     const uint64_t total = b->h_dout_off[nb];
-    if (total) {
-        if ((rc = b->h_stage.ensure((size_t)total)) != 0) return rc;
-        HIP_TRY(hipMemcpyAsync(b->h_stage.p, b->d_dout.p, (size_t)total, hipMemcpyDeviceToHost, sm));
-        HIP_TRY(hipStreamSynchronize(sm));
+    uint64_t used = 0;
+    bool same_layout = true;
+    for (uint32_t k = 0; k < nb; ++k) {
+        const uint64_t cap = out_off[k + 1] - out_off[k];
+        if (sts[k] == 0 && lens[k] > cap) sts[k] = MI355_LZSS_E_CAPACITY;
+        if (sts[k] == 0) used += lens[k];
+        if (out_off[k] - out_off[0] != b->h_dout_off[k] || cap != b->h_dout_off[k + 1] - b->h_dout_off[k]) same_layout = false;
     }
+    if (same_layout && total && used * 2 >= total) {
+        HIP_TRY(hipMemcpyAsync(out + out_off[0], b->d_dout.p, (size_t)total, hipMemcpyDeviceToHost, sm));
+    } else {
+        for (uint32_t k = 0; k < nb; ++k)
+            if (sts[k] == 0 && lens[k])
+                HIP_TRY(hipMemcpyAsync(out + out_off[k], b->d_dout.as<uint8_t>() + b->h_dout_off[k], lens[k], hipMemcpyDeviceToHost, sm));
+    }
+    HIP_TRY(hipStreamSynchronize(sm));
     int worst = 0;
     for (uint32_t k = 0; k < nb; ++k) {
-        int32_t st = sts[k];
-        const uint64_t cap = out_off[k + 1] - out_off[k];
-        if (st == 0 && lens[k] > cap) st = MI355_LZSS_E_CAPACITY;
-        if (st == 0 && lens[k]) memcpy(out + out_off[k], b->h_stage.as<uint8_t>() + b->h_dout_off[k], lens[k]);
-        if (out_len) out_len[k] = st == 0 ? lens[k] : 0;
-        if (status) status[k] = st;
-        if (st && !worst) worst = st;
+        if (out_len) out_len[k] = sts[k] == 0 ? lens[k] : 0;
+        if (status) status[k] = sts[k];
+        if (sts[k] && !worst) worst = sts[k];
     }
     if (worst && !status) return fail(worst, "blob failed with status %d", worst);
     return 0;
@@ -880,8 +1261,16 @@ extern "C" int mi355_lzss_decompress_batch(mi355_lzss_ctx *ctx, const uint8_t *i
                                            uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
     if (!ctx || !in_off || !out_off) return fail(MI355_LZSS_E_ARG, "null argument");
     int rc;
+    if ((rc = set_device(ctx)) != 0) return rc;
+    if ((rc = ensure_scratch(ctx)) != 0) return rc;
     mi355_lzss_batch *b = ctx->scratch;
     if ((rc = mi355_lzss_batch_upload_compressed(b, in, in_off, n_blobs, out_off)) != 0) return rc;
     if ((rc = mi355_lzss_batch_decompress(b)) != 0) return rc;
     return mi355_lzss_batch_download_decompressed(b, out, out_off, out_len, status);
+}
+
+extern "C" int mi355_lzss_decompress_batch_multi(mi355_lzss_ctx *const *ctxs, int n_ctx, const uint8_t *in, const uint64_t *in_off,
+                                                 uint32_t n_blobs, uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
+                                                 int32_t *status) {
+    return run_multi(mi355_lzss_decompress_batch, ctxs, n_ctx, in, in_off, n_blobs, out, out_off, out_len, status);
 }

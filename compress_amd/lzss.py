@@ -80,11 +80,13 @@ class Header:
 class _Ctx:
     """One dictionary on one device (mi355_lzss_ctx)."""
 
-    def __init__(self, dict_: bytes, device: int = 0):
+    def __init__(self, dict_: bytes, device: int = 0, decoder: bool = False):
         d = _as_u8(dict_ or b"")
         h = C.c_void_p()
-        _check(_lib.lib().mi355_lzss_ctx_create(_ptr(d) if d.size else None, d.size, device, C.byref(h)))
+        create = _lib.lib().mi355_lzss_ctx_create_decoder if decoder else _lib.lib().mi355_lzss_ctx_create
+        _check(create(_ptr(d) if d.size else None, d.size, device, C.byref(h)))
         self.h = h
+        self.device = device
         n = C.c_uint64()
         idx = (C.c_int32 * 2)()
         _check(_lib.lib().mi355_lzss_dict_info(self.h, C.byref(n), C.byref(idx)))
@@ -94,6 +96,10 @@ class _Ctx:
     def set_overlap(self, parts: int):
         """run the index / match stages of this context's batches as `parts` concurrent sub-batches (tuning knob)"""
         _check(_lib.lib().mi355_lzss_ctx_set_overlap(self.h, int(parts)))
+
+    def set_chunk_bytes(self, nbytes: int):
+        """chunk size of the copy / compute / copy pipeline behind compress_batch (tuning knob)"""
+        _check(_lib.lib().mi355_lzss_ctx_set_chunk_bytes(self.h, int(nbytes)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -227,6 +233,20 @@ class Compressor:
         _check(_lib.lib().mi355_lzss_compressed_size(self._ctx.h, _ptr(a) if a.size else None, a.size, C.byref(size)))
         return size.value
 
+    def CompressedSizes256k(self, blobs):
+        """CompressedSize256k of many independent inputs in one launch sequence (mi355_lzss_compressed_size_batch)"""
+        if self._no_compression:
+            return [HeaderSize + len(b) for b in blobs]
+        flat, off = _csr(blobs)
+        sizes = np.zeros(max(len(blobs), 1), dtype=np.uint64)
+        _check(_lib.lib().mi355_lzss_compressed_size_batch(self._ctx.h, _ptr(flat) if flat.size else None, _ptr(off),
+                                                           len(blobs), _ptr(sizes), None))
+        return [int(x) for x in sizes[:len(blobs)]]
+
+    def Close(self):
+        """releases the device side (the Go shim's Close; the reference has no device to release)"""
+        self._ctx.close()
+
     # -- diagnostics: the per-position hot path (compress.go:146-173)
     def best_backrefs(self, d: bytes, start: int = 0):
         a = _as_u8(d)
@@ -249,6 +269,85 @@ def _csr(blobs):
     np.cumsum([len(b) for b in blobs], out=off[1:])
     flat = np.frombuffer(b"".join(bytes(b) for b in blobs), dtype=np.uint8) if len(blobs) else np.zeros(0, np.uint8)
     return flat, off
+
+
+class PinnedBuffer:
+    """A numpy uint8 view of pinned host memory (mi355_lzss_host_alloc): batch buffers placed here move by DMA."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = max(int(nbytes), 1)
+        self.ptr = _lib.lib().mi355_lzss_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise LzssError(_lib.last_error(), _lib.E_DEVICE)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            _lib.lib().mi355_lzss_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def partition(in_off, n_parts: int):
+    """contiguous blob ranges balanced by bytes, as the multi-device entry points cut a batch (mi355_lzss_partition)"""
+    off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    first = np.zeros(n_parts + 1, dtype=np.uint32)
+    _check(_lib.lib().mi355_lzss_partition(_ptr(off), off.size - 1, n_parts, _ptr(first)))
+    return [int(x) for x in first]
+
+
+def _ctx_array(ctxs):
+    hs = [(c._ctx if isinstance(c, Compressor) else c).h for c in ctxs]
+    return (C.c_void_p * len(hs))(*[h.value for h in hs])
+
+
+def compress_batch_multi(ctxs, blobs):
+    """compress_batch over several contexts (one per GPU of the node) in one call: mi355_lzss_compress_batch_multi"""
+    flat, off = _csr(blobs)
+    nb = len(blobs)
+    caps = [HeaderSize + (37 * len(b) + 7) // 8 + 1 for b in blobs]
+    out_off = np.zeros(nb + 1, dtype=np.uint64)
+    np.cumsum(caps, out=out_off[1:])
+    out = np.zeros(max(int(out_off[-1]), 1), dtype=np.uint8)
+    out_len = np.zeros(max(nb, 1), dtype=np.uint32)
+    status = np.zeros(max(nb, 1), dtype=np.int32)
+    _check(_lib.lib().mi355_lzss_compress_batch_multi(_ctx_array(ctxs), len(ctxs), _ptr(flat) if flat.size else None, _ptr(off),
+                                                      nb, _ptr(out), _ptr(out_off), _ptr(out_len), _ptr(status)))
+    res = []
+    for k in range(nb):
+        if status[k] != 0:
+            raise LzssError(f"blob {k}: status {status[k]}", int(status[k]))
+        o = int(out_off[k])
+        res.append(out[o:o + int(out_len[k])].tobytes())
+    return res
+
+
+def decompress_batch_multi(ctxs, blobs, max_out_len):
+    """decompress_batch over several contexts in one call: mi355_lzss_decompress_batch_multi"""
+    flat, off = _csr(blobs)
+    nb = len(blobs)
+    caps = [max_out_len] * nb if np.isscalar(max_out_len) else list(max_out_len)
+    out_off = np.zeros(nb + 1, dtype=np.uint64)
+    np.cumsum(caps, out=out_off[1:])
+    out = np.zeros(max(int(out_off[-1]), 1), dtype=np.uint8)
+    out_len = np.zeros(max(nb, 1), dtype=np.uint32)
+    status = np.zeros(max(nb, 1), dtype=np.int32)
+    _check(_lib.lib().mi355_lzss_decompress_batch_multi(_ctx_array(ctxs), len(ctxs), _ptr(flat) if flat.size else None,
+                                                        _ptr(off), nb, _ptr(out), _ptr(out_off), _ptr(out_len), _ptr(status)))
+    res = []
+    for k in range(nb):
+        if status[k] != 0:
+            res.append(LzssError(f"blob {k}: status {status[k]}", int(status[k])))
+        else:
+            o = int(out_off[k])
+            res.append(out[o:o + int(out_len[k])].tobytes())
+    return res
 
 
 def compress_batch(ctx_or_compressor, blobs):
@@ -308,12 +407,28 @@ def Decompress(data: bytes, dict_: bytes = b"", device: int = 0) -> bytes:
         raise LzssError("unsupported compressor version")
     if h.NoCompression:
         return data[HeaderSize:]
-    ctx = _Ctx(dict_ or b"", device)
-    try:
-        cap = max(16, (len(data) - HeaderSize) * 8 // 30 * 256 + 512)
-        r = decompress_batch(ctx, [data], min(cap, 1 << 28))[0]
-    finally:
-        ctx.close()
+    ctx = _decoder_ctx(bytes(dict_ or b""), device)
+    cap = max(16, (len(data) - HeaderSize) * 8 // 30 * 256 + 512)
+    r = decompress_batch(ctx, [data], min(cap, 1 << 28))[0]
     if isinstance(r, LzssError):
         raise r
     return r
+
+
+# Decompress builds no index in the reference (decompress.go:34 only augments the dictionary): a decode-only
+# context per (dictionary, device), kept in a small LRU so that a caller that decompresses in a loop pays the
+# dictionary upload once
+_DECODERS = {}
+_DECODERS_MAX = 4
+
+
+def _decoder_ctx(dict_: bytes, device: int):
+    import hashlib
+    key = (hashlib.sha256(dict_).digest(), len(dict_), device)
+    ctx = _DECODERS.pop(key, None)
+    if ctx is None:
+        ctx = _Ctx(dict_, device, decoder=True)
+        while len(_DECODERS) >= _DECODERS_MAX:
+            _DECODERS.pop(next(iter(_DECODERS))).close()
+    _DECODERS[key] = ctx   # most recently used last
+    return ctx

@@ -11,7 +11,8 @@
  *  - return value: 0 = MI355_LZSS_OK, negative = error; mi355_lzss_last_error() gives the text.
  *    Where the reference has an error text, the same text is used
  *    ("dict size must be <= 4194304", "input size must be <= 4194304");
- *  - a ctx / batch is NOT thread-safe (like lzss.Compressor); use one per thread / goroutine.
+ *  - a ctx / batch is NOT thread-safe (like lzss.Compressor); use one per thread / goroutine - except
+ *    mi355_lzss_compressed_size(_batch), which is (like CompressedSize256k, compress.go:381-383).
  *    Objects created on different devices are independent;
  *  - there is no CPU fallback: without a usable HIP device every entry point fails with
  *    MI355_LZSS_E_DEVICE.
@@ -41,6 +42,10 @@ typedef struct mi355_lzss_batch mi355_lzss_batch; /* device workspace for batche
  * suffixarray.New(dict) (:64) - the dictionary index is built on the device. */
 int  mi355_lzss_ctx_create(const uint8_t *dict, size_t dict_len, int device, mi355_lzss_ctx **out);
 void mi355_lzss_ctx_destroy(mi355_lzss_ctx *ctx);
+/* A context for Decompress only (lzss/decompress.go:34: the decoder augments the dictionary and builds
+ * no index): the augmented dictionary's text goes to the device, nothing else is built or allocated
+ * until a decompress entry point runs.  Every compress entry point fails with MI355_LZSS_E_ARG on it. */
+int  mi355_lzss_ctx_create_decoder(const uint8_t *dict, size_t dict_len, int device, mi355_lzss_ctx **out);
 /* last error text of this thread (valid until the next failing call on the thread) */
 const char *mi355_lzss_last_error(void);
 /* Tuning knob with no counterpart in the reference: batches of this context run their index / match stages as
@@ -49,6 +54,16 @@ const char *mi355_lzss_last_error(void);
  * parts == 1.  Default: 2 (batches of fewer than 8 blobs per part, or with a text of 512 KiB or more, always run as
  * one part), or the environment variable MI355_LZSS_SPLIT when the context is created. */
 int  mi355_lzss_ctx_set_overlap(mi355_lzss_ctx *ctx, int parts);
+/* Tuning knob with no counterpart in the reference: the host-buffer batch entry points
+ * (mi355_lzss_compress_batch, ..._multi) cut a batch into chunks of about this many input bytes and run
+ * them as a pipeline - chunk k+1 goes up and chunk k-1 comes down while chunk k computes.  Default
+ * 160 MiB (1250 blobs of 128 KiB); results do not depend on it. */
+int  mi355_lzss_ctx_set_chunk_bytes(mi355_lzss_ctx *ctx, uint64_t bytes);
+/* Pinned host memory (hipHostMalloc) for callers that want their batch buffers to move by DMA: with
+ * `in` / `out` of the batch entry points allocated here the copies overlap with the kernels.  Pageable
+ * buffers work too (the HIP runtime stages them).  No counterpart in the reference. */
+void *mi355_lzss_host_alloc(size_t bytes);
+void  mi355_lzss_host_free(void *p);
 /* length of the augmented dictionary and the two reserved-symbol indices ([0]=0xFE, [1]=0xFF) */
 int  mi355_lzss_dict_info(const mi355_lzss_ctx *ctx, uint64_t *aug_len, int32_t reserved_idx[2]);
 
@@ -85,8 +100,16 @@ int mi355_lzss_write_noalloc(mi355_lzss_ctx *ctx, const uint8_t *d_inbuf, size_t
                              unsigned bit_off, uint8_t *d_out, size_t out_cap, uint64_t *d_nbits,
                              int32_t *d_status, void *stream);
 
-/* CompressedSize256k (lzss/compress.go:384-407): 3 + ceil(bits/8) of write(d, 0); n <= 256 KiB */
+/* CompressedSize256k (lzss/compress.go:384-407): 3 + ceil(bits/8) of write(d, 0); n <= 256 KiB.
+ * Like the reference's ("state less and thread-safe", compress.go:381-383) this entry point - and only
+ * this one and its batch form - may be called on one ctx from several threads at once: every call
+ * works in a workspace of its own (own stream, own buffers) taken from a pool of the ctx. */
 int mi355_lzss_compressed_size(mi355_lzss_ctx *ctx, const uint8_t *d, size_t n, uint64_t *size);
+/* the same for n_blobs independent inputs in one launch sequence (CSR offsets, n_blobs+1 entries);
+ * sizes[b] = CompressedSize256k(blob b); status[b] = 0 or MI355_LZSS_E_INPUT_SIZE (blob > 256 KiB;
+ * with status == NULL such a blob fails the call) */
+int mi355_lzss_compressed_size_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off,
+                                     uint32_t n_blobs, uint64_t *sizes, int32_t *status);
 
 /* ---- batches of independent blobs ------------------------------------------------------------
  * One-shot Compress (lzss/compress.go:375-379 = Reset + Write + Bytes) of n_blobs independent
@@ -98,10 +121,28 @@ int mi355_lzss_compress_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint
                               uint32_t *out_len, int32_t *status);
 
 /* Decompress (lzss/decompress.go:17-84) of n_blobs independent streams with the ctx dictionary.
- * out_len[b] = decompressed size; status[b] = 0, MI355_LZSS_E_FORMAT or MI355_LZSS_E_CAPACITY. */
+ * out_len[b] = decompressed size; status[b] = 0, MI355_LZSS_E_FORMAT or MI355_LZSS_E_CAPACITY.
+ * The bytes of out[out_off[b]:out_off[b+1]) beyond out_len[b] are unspecified after the call. */
 int mi355_lzss_decompress_batch(mi355_lzss_ctx *ctx, const uint8_t *in, const uint64_t *in_off,
                                 uint32_t n_blobs, uint8_t *out, const uint64_t *out_off,
                                 uint32_t *out_len, int32_t *status);
+
+/* ---- one call, several GPUs -------------------------------------------------------------------
+ * The two batch operations over n_ctx contexts (one per device of the node, all with the same
+ * dictionary): the blobs are cut into n_ctx contiguous ranges balanced by input bytes
+ * (mi355_lzss_partition), every range runs on its context from a host thread of its own, results land
+ * in the caller's CSR buffers; no collective, no peer traffic - blobs are independent (each Compress
+ * starts from Reset, compress.go:375-376).  No counterpart in the reference (single-threaded). */
+int mi355_lzss_compress_batch_multi(mi355_lzss_ctx *const *ctxs, int n_ctx, const uint8_t *in,
+                                    const uint64_t *in_off, uint32_t n_blobs, uint8_t *out,
+                                    const uint64_t *out_off, uint32_t *out_len, int32_t *status);
+int mi355_lzss_decompress_batch_multi(mi355_lzss_ctx *const *ctxs, int n_ctx, const uint8_t *in,
+                                      const uint64_t *in_off, uint32_t n_blobs, uint8_t *out,
+                                      const uint64_t *out_off, uint32_t *out_len, int32_t *status);
+/* the partition they use (host only, no device needed): first[t] = first blob of part t, n_parts+1
+ * entries, first[n_parts] = n_blobs; part t starts at the first blob whose offset reaches t/n_parts of
+ * the bytes */
+int mi355_lzss_partition(const uint64_t *off, uint32_t n_blobs, int n_parts, uint32_t *first);
 
 /* ---- device-resident batches (what bench.py times) -------------------------------------------
  * The same two operations split into upload / run / download so that a caller can keep inputs

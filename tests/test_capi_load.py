@@ -80,3 +80,24 @@ def test_synth_statistics():
         if b == 0:
             assert min(st["literals"], st["short"], st["long_data"], st["long_dict"], st["rle"]) > 0
     assert synth.blob(0) == synth.blob(0) and synth.blob(0) != synth.blob(1)
+
+
+def test_partition_is_host_only_and_balanced():
+    """the blob -> device partition of the multi-device entry points (mi355_lzss_partition) needs no GPU: contiguous
+    ranges, every blob in exactly one, balanced by bytes"""
+    import numpy as np
+    import compress_amd
+    rng = np.random.default_rng(1)
+    for n_blobs in (0, 1, 5, 1000):
+        lens = rng.integers(0, 200000, n_blobs)
+        off = np.concatenate([[7], 7 + np.cumsum(lens)]).astype(np.uint64)   # offsets need not start at 0
+        for parts in (1, 2, 3, 8):
+            first = compress_amd.partition(off, parts)
+            assert first[0] == 0 and first[-1] == n_blobs and len(first) == parts + 1
+            assert all(a <= b for a, b in zip(first, first[1:]))
+            if n_blobs == 1000:
+                sizes = [int(off[first[t + 1]] - off[first[t]]) for t in range(parts)]
+                assert max(sizes) - min(sizes) <= 2 * 200000
+    # equal blobs: equal shares (config 3: 10 000 blobs over 8 GPUs = 1250 each)
+    off = (np.arange(10001, dtype=np.uint64) * 131072)
+    assert compress_amd.partition(off, 8) == [1250 * t for t in range(9)]
