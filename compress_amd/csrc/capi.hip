@@ -130,7 +130,7 @@ struct mi355_lzss_batch {
     uint64_t cap_elems = 0;  // element capacity of the per-position arrays
     // per-position arrays
     DevBuf text, sortA, sortB, rkA, rkB, flags, rlen, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
-    DevBuf pmin1, pmax1, pmin2, pmax2, samin1, samin2;  // per 64 entries
+    DevBuf pmin1, pmax1, pmin2, pmax2, samin1, samin2, dlb;  // per 64 entries
     DevBuf cdir;                                        // per 64 ranks and chunk
     DevBuf tbits;                   // per position
     DevBuf entry, tilebit;          // per 256-tile
@@ -175,7 +175,7 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
         const uint64_t e64 = e / 64 + 1, e256 = e / 256 + 1;
         if ((rc = b->b1.ensure(e64 * 2)) != 0) return rc;
         if ((rc = b->b2.ensure(e64 * 2)) != 0) return rc;
-        for (DevBuf *d : {&b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2})
+        for (DevBuf *d : {&b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->dlb})
             if ((rc = d->ensure(e64 * 4)) != 0) return rc;
         if ((rc = b->entry.ensure(e256 * 2)) != 0) return rc;
         if ((rc = b->tilebit.ensure(e256 * 8)) != 0) return rc;
@@ -215,6 +215,7 @@ static BatchIndex batch_index(mi355_lzss_batch *b) {
     ix.pmin1 = b->pmin1.as<int32_t>(); ix.pmax1 = b->pmax1.as<int32_t>();
     ix.pmin2 = b->pmin2.as<int32_t>(); ix.pmax2 = b->pmax2.as<int32_t>();
     ix.samin1 = b->samin1.as<int32_t>(); ix.samin2 = b->samin2.as<int32_t>();
+    ix.dlb = b->dlb.as<int32_t>();
     ix.cdir = b->cdir.as<uint16_t>();
     ix.nch = std::max<uint32_t>(1, (b->max_n + LZSS_SHORT_WINDOW - 1) / LZSS_SHORT_WINDOW);
     return ix;
@@ -270,7 +271,7 @@ extern "C" void mi355_lzss_batch_destroy(mi355_lzss_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     DevBuf *bufs[] = {&b->text, &b->sortA, &b->sortB, &b->rkA, &b->rkB, &b->flags, &b->rlen, &b->sa, &b->isa,
-                      &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->cdir, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
+                      &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->dlb, &b->cdir, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
                       &b->tbits, &b->segs, &b->src_off, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->flat, &b->out,
                       &b->d_cin, &b->d_cin_off, &b->d_dout, &b->d_dout_off, &b->d_dlen, &b->d_dstatus};
     for (DevBuf *d : bufs) d->release();
@@ -658,7 +659,7 @@ static int noalloc_bind(mi355_lzss_ctx *ctx) {
     take(b->sa, e * 4); take(b->isa, e * 4); take(b->lcp, e * 2); take(b->res, e * 4);
     take(b->adv, e); take(b->kind, e); take(b->exitoff, e); take(b->tbits, e * 2);
     take(b->b1, e64 * 2); take(b->b2, e64 * 2);
-    for (DevBuf *d : {&b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2}) take(*d, e64 * 4);
+    for (DevBuf *d : {&b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->dlb}) take(*d, e64 * 4);
     take(b->cdir, e64 * nch * 2);
     take(b->entry, e256 * 2); take(b->tilebit, e256 * 8);
     take(b->segs, sizeof(Seg)); take(b->nbits, 8); take(b->out_off, 16); take(b->out_len, 4); take(b->status, 4);

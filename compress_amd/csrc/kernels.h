@@ -51,6 +51,7 @@ struct BatchIndex {   // batch-wide index arrays
     int32_t *pmin1, *pmax1;  // min / max of ps over blocks of 64 entries   [seg.off/64 + j/64]
     int32_t *pmin2, *pmax2;  // ... over blocks of 4096 entries             [seg.off/64 + j/4096]
     int32_t *samin1, *samin2;  // min of sa over blocks of 64 / 4096 ranks  [seg.off/64 + k/64], [.. + k/4096]
+    int32_t *dlb;     // [seg.off/64 + b] lower bound in the DICTIONARY's suffix array of the pattern at rank 64 b (match.hip)
     // chunk directory: cdir[(seg.off/64 + b) * nch + c] = entries of chunk c whose rank is < 1 + 64 b, so the first
     // entry of a chunk with rank >= lo is a few entries past cdir[(lo - 1) / 64] instead of a binary search away
     uint16_t *cdir;

@@ -247,18 +247,20 @@ __device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen
 // Binary search of pat[0:maxLen) among the dictionary suffixes.  Invariant: suffix(lo) < pat <= suffix(hi); rank 0 is
 // the sentinel, rank n+1 is virtual.  Narrows [lo, hi] until hi == lo + 1; hi is then the lower bound of pat.
 // pk / prl: run_key of the pattern and the run length it vouches for.
-__device__ inline void dict_search(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int &lo, int &hi) {
+template <class KeyAt, class SaAt>
+__device__ inline void dict_search_in(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int &lo, int &hi,
+                                      KeyAt key_at, SaAt sa_at) {
     int llo = 0, lhi = 0;  // lower bounds of lcp(pat, suffix(lo)) / lcp(pat, suffix(hi)) from text compares
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        const uint64_t kq = D.key[mid];
+        const uint64_t kq = key_at(mid);
         bool suffix_less;
         int o = 0;
         DS(2, 1)
         if (kq != pk) {
             suffix_less = kq < pk;  // the key order is the string order
         } else {
-            const int q = D.SA[mid];
+            const int q = sa_at(mid);
             const int avail = (int)D.n - q;
             const int lim = maxLen < avail ? maxLen : avail;
             o = llo < lhi ? llo : lhi;
@@ -272,6 +274,9 @@ __device__ inline void dict_search(const DictView &D, const uint8_t *pat, int ma
         }
         if (suffix_less) { lo = mid; llo = o; } else { hi = mid; lhi = o; }
     }
+}
+__device__ inline void dict_search(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int &lo, int &hi) {
+    dict_search_in(D, pat, maxLen, pk, prl, lo, hi, [&](int k) { return D.key[k]; }, [&](int k) { return D.SA[k]; });
 }
 
 // the bracket of every suffix sharing two bytes with pat; false if there is none
@@ -324,6 +329,72 @@ __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int ma
     // the smallest-rank occurrence is the first rank of the interval of suffixes sharing Ld bytes with rank kd
     // (dict_occurrence); when hi alone attains Ld that is hi itself (LCP[hi] = lcp with lo < Ld)
     kd = lhi > llo ? hi : lo;
+}
+// Lower bound of pat[0:maxLen) among the dictionary suffixes (the `hi` the binary search ends on).
+__device__ inline int dict_lower_bound(const DictView &D, const uint8_t *pat, int maxLen, int run, uint64_t w0) {
+    int lo = 0, hi = (int)D.n + 1, prl;
+    const uint64_t pk = run_key_w(pat, maxLen, prl, run, w0);
+    if (maxLen >= 2) (void)dict_bucket(D, w0, lo, hi);
+    if (prl >= 2) {
+        const int2 se = D.bkt[DICT_PAIR_BUCKETS + (uint32_t)(pk >> 40)];
+        if (se.x < se.y) {
+            lo = lo > se.x - 1 ? lo : se.x - 1;
+            hi = hi < se.y ? hi : se.y;
+        }
+    }
+    dict_search(D, pat, maxLen, pk, prl, lo, hi);
+    return hi;
+}
+
+// The patterns of a text are SORTED in suffix-rank order (a pattern is the suffix cut at maxLen <= 256, which keeps
+// the order), so their lower bounds in the dictionary are monotone in the rank.  dict_bounds_kernel searches the
+// dictionary for every 64th rank only (one lane per block of 64 ranks: dense waves, 1 / 64 of the probes);
+// match_kernel's wave of ranks [64 b, 64 b + 64) then knows that all its lower bounds lie between dlb[b] and
+// dlb[b + 1], stages the keys and suffix-array entries of that stretch of the dictionary in LDS with coalesced loads
+// and every lane finishes its search there - no scattered probes at all.  Brackets wider than DICT_WIN ranks (a
+// block in a stretch where the dictionary is much denser than the text) search global memory inside the bracket.
+constexpr int DICT_WIN = 256;
+__global__ __launch_bounds__(64) void dict_bounds_kernel(const Seg *segs, uint32_t nblk_max, BatchIndex ix, DictView D, int32_t *dlb) {
+    const Seg sg = segs[blockIdx.y];
+    const uint32_t N = sg.n + 1, nblk = (N + 63) / 64;
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= nblk) return;
+    int lb = 1;  // rank 0 is the text's end sentinel: the empty pattern
+    if (b > 0) {
+        const uint32_t i = (uint32_t)ix.sa[sg.off + 64 * b];
+        const int maxLen = (int)(sg.n - i) < LZSS_MAX_LEN ? (int)(sg.n - i) : LZSS_MAX_LEN;
+        const uint8_t *pat = ix.text + sg.off + i;
+        lb = dict_lower_bound(D, pat, maxLen, (int)ix.rlen[sg.off + i], ld8(pat));
+    }
+    dlb[sg.off / 64 + b] = lb;
+}
+
+// hF / hL: lower bounds of the block's first rank and of the next block's first rank (D.n + 1 past the last block)
+__device__ inline void dict_lookup_wave(const DictView &D, const uint64_t *s_key, const int32_t *s_dsa, bool staged, int LB, int hL,
+                                        bool need, const uint8_t *pat, int maxLen, int &Ld, int &kd, int run, uint64_t w0 MP_ARG) {
+    Ld = 0;
+    kd = 0;
+    if (!need) return;
+    int prl = 0;
+    const uint64_t pk = run_key_w(pat, maxLen, prl, run, w0);
+    int lo = LB, hi = hL;
+    int q2[2];
+    uint64_t k2[2];
+    if (staged) {
+        dict_search_in(D, pat, maxLen, pk, prl, lo, hi, [&](int k) { return s_key[k - LB]; }, [&](int k) { return s_dsa[k - LB]; });
+        q2[0] = s_dsa[lo - LB]; q2[1] = s_dsa[lo - LB + 1];
+        k2[0] = s_key[lo - LB]; k2[1] = s_key[lo - LB + 1];
+    } else {
+        dict_search(D, pat, maxLen, pk, prl, lo, hi);
+        __builtin_memcpy(q2, D.SA + lo, 8);
+        __builtin_memcpy(k2, D.key + lo, 16);
+    }
+    MP(13)
+    const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo, q2[0], k2[0]);
+    const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi, q2[1], k2[1]);
+    Ld = llo > lhi ? llo : lhi;
+    kd = lhi > llo ? hi : lo;
+    MP(14)
 }
 __device__ inline int dict_occurrence(const DictView &D, int kd, int Ld) {
     return D.SA[prev_lower(D.LCP, D.bmin1, D.bmin2, kd, Ld)];
@@ -381,7 +452,8 @@ __device__ inline int wave_incl_min(int v, int lane) {
 // for a few (heavy tail), so a lane walks SCAN_CAP x 4 ranks alone; whatever is left is finished by the
 // whole wave, 64 ranks per step (coalesced loads, prefix-min of LCP across lanes, ballot for the first hit).
 __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, BatchIndex ix,
-                                                              DictView D, uint32_t *res, int skip_unqueried, int defer, int ablate) {
+                                                              DictView D, const int32_t *dlb, uint32_t *res, int skip_unqueried, int defer,
+                                                              int ablate) {
     const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);
     if (vb >= gx * n_segs) return;
     const uint32_t bx = vb % gx;
@@ -401,6 +473,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     static_assert(MATCH_THREADS == 64, "one wave per block: the window belongs to the wave");
     __shared__ int32_t s_sa[WIN_TOTAL + 4];
     __shared__ uint32_t s_lc[WIN_TOTAL + 4];
+    __shared__ uint64_t s_dkey[DICT_WIN + 2];  // the wave's bracket of the dictionary (dict_lookup_wave)
+    __shared__ int32_t s_dsa[DICT_WIN + 2];
     const int wbase = (int)(bx * MATCH_THREADS) - WIN_HALO;
     for (int j = lane; j < WIN_TOTAL; j += 64) {
         int g = wbase + j;
@@ -411,6 +485,17 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     if (lane < 4) {  // what a lane that has finished reads: outside every window, an lcp that changes nothing
         s_sa[WIN_TOTAL + lane] = 0x7FFFFFFF;
         s_lc[WIN_TOTAL + lane] = 0xFFFFu;
+    }
+    // the block's stretch of the dictionary (dict_bounds_kernel): ranks dLB .. dhL hold every lane's (lo, hi) pair
+    const int nblk = (N + 63) >> 6;
+    const int dLB = dlb[sg.off / 64 + bx] - 1;
+    const int dhL = (int)bx + 1 < nblk ? dlb[sg.off / 64 + bx + 1] : (int)D.n + 1;
+    const bool dstaged = dhL - dLB + 1 <= DICT_WIN;
+    if (dstaged) {
+        for (int j = lane; j <= dhL - dLB; j += 64) {
+            s_dkey[j] = D.key[dLB + j];
+            s_dsa[j] = D.SA[dLB + j];
+        }
     }
     __syncthreads();
     bool work = r >= 1 && r < N;
@@ -610,11 +695,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
         upL = lu > ld;
     }
     MP(5)
-    // dictionary (compress.go:460-466): every lane searches on its own.  (Sharing the search between the lanes of a
-    // wave - their lower bounds are monotone in rank - was measured slower: the phases serialise the probe latency
-    // and a divergent probe loop costs the same issue slots however few lanes run it.)
+    // dictionary (compress.go:460-466): the lanes' patterns are sorted, so the wave brackets them between the lower
+    // bounds of its first and last lane and finishes inside LDS (dict_lookup_wave)
     int Ld = 0, kd = 0;
-    if (work && dynOK && LL < maxLen && !(ablate & 1)) dict_lookup(D, T + i, maxLen, minD, 0, (int)D.n + 1, Ld, kd, (int)((rl4 >> 16) & 0xFFu), w0 MP_PASS);
+    dict_lookup_wave(D, s_dkey, s_dsa, dstaged, dLB, dhL, work && dynOK && LL < maxLen && !(ablate & 1), T + i, maxLen, Ld, kd,
+                     (int)((rl4 >> 16) & 0xFFu), w0 MP_PASS);
     MP(7)
     // selection (compress.go:160-169) BEFORE the offsets: only the window whose reference is emitted needs its
     // smallest-rank occurrence, so every lane runs at most one interval search
@@ -711,8 +796,9 @@ void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const Batc
     const uint32_t gx = (max_n + 1 + MATCH_THREADS - 1) / MATCH_THREADS;  // blocks per segment
     // for_emit: the results feed the phrase walk and the emitter only (not the per-position debug view)
     const int defer = (skip_unqueried && !no_defer && max_n + 1 < RES_DEFER_MAX_N) ? 1 : 0;
+    hipLaunchKernelGGL(dict_bounds_kernel, dim3((gx + 63) / 64, n_segs), dim3(64), 0, stream, d_segs, gx, ix, dict, ix.dlb);
     hipLaunchKernelGGL(match_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(MATCH_THREADS), 0, stream, d_segs, n_segs, gx,
-                       ix, dict, d_res, skip_unqueried ? 1 : 0, defer, ablate);
+                       ix, dict, ix.dlb, d_res, skip_unqueried ? 1 : 0, defer, ablate);
 }
 
 }  // namespace lzss

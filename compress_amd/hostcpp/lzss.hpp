@@ -197,8 +197,9 @@ inline Bytes Decompress(const Bytes &data, const Bytes &dict, int device = 0, si
     }
     if (h.Version != lzss::Version) throw Error("unsupported compressor version");
     if (h.NoCompression) return Bytes(data.begin() + HeaderSize, data.end());
+    // a decode-only context: the dictionary's text on the device, no index (decompress.go:34 only augments the dictionary)
     mi355_lzss_ctx *ctx = nullptr;
-    check(mi355_lzss_ctx_create(dict.empty() ? nullptr : dict.data(), dict.size(), device, &ctx));
+    check(mi355_lzss_ctx_create_decoder(dict.empty() ? nullptr : dict.data(), dict.size(), device, &ctx));
     size_t cap = (data.size() - HeaderSize) * 8 / 30 * 256 + 512;
     if (cap > max_out) cap = max_out;
     Bytes out(cap);

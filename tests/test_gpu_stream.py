@@ -48,3 +48,17 @@ def test_pack_stream_with_incompressible_stretches(dict_naive):
     want = stream.pack_stream_sequential(OracleCompressor(dict_naive), data, 1000, 5000)
     got = stream.pack_stream(compress_amd.Compressor(dict_naive), data, 1000, 5000, 16)
     assert got == want
+
+
+def test_pack_stream_at_config4_cap(dict_naive):
+    """BASELINE config 4's real cap: 1000-byte Writes into blobs of <= 126 976 B (4096 x 31, the payload of one
+    EIP-4844 blob).  One such blob takes ~430 KB of calldata-like input, i.e. ~430 Writes that each re-index the whole
+    inBuf - the oracle loop needs a while for it, so one full blob and the start of the next are checked."""
+    import compress_amd
+    from compress_amd import stream, synth
+    data = b"".join(synth.blob(400 + k) for k in range(4))[:470000]
+    want = stream.pack_stream_sequential(OracleCompressor(dict_naive), data, 1000, 126976)
+    got = stream.pack_stream(compress_amd.Compressor(dict_naive), data, 1000, 126976)
+    assert [n for _, n in got] == [n for _, n in want]
+    assert got == want
+    assert len(got) == 2 and 126976 - 40 <= len(got[0][0]) <= 126976
