@@ -231,7 +231,8 @@ void launch_dict_aux(const uint8_t *d_text, uint32_t n, const int32_t *d_sa, uin
 
 // exact common prefix of pat[0:maxLen) and the dictionary suffix of rank k (0 for the sentinel / virtual ranks):
 // from the keys when they differ, else by comparing text past the run the equal keys vouch for
-__device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int k, int q, uint64_t kq) {
+__device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int k, int q, uint64_t kq,
+                               int known = -1) {
     if (k < 1 || k > (int)D.n) return 0;  // q = SA[k], kq = key[k] (whatever the arrays hold for the virtual rank n + 1)
     const int avail = (int)D.n - q;
     const int lim = maxLen < avail ? maxLen : avail;
@@ -239,23 +240,47 @@ __device__ inline int dict_lcp(const DictView &D, const uint8_t *pat, int maxLen
         const int l = key_lcp(pk, kq);
         return l < lim ? l : lim;
     }
+    if (known >= 0) return known;  // the search compared this very suffix (dict_search_in)
     const int l_ = lcp_bytes(pat, D.T + q, prl < lim ? prl : lim, lim);
     DS(5, 1) DS(6, (l_ - (prl < lim ? prl : lim)) / 8 + 1)
     return l_;
 }
 
+// common prefix length of a and b from `from` on, at most lim (both readable 8 bytes past lim); b_less: whether b's byte
+// at the first difference is the smaller one (meaningful when the result is < lim) - read off the words the compare
+// loaded, no further load
+__device__ inline int lcp_cmp(const uint8_t *a, const uint8_t *b, int from, int lim, bool &b_less) {
+    int o = from;
+    b_less = false;
+    while (o < lim) {
+        const uint64_t wa = ld8(a + o), wb = ld8(b + o);
+        const uint64_t x = wa ^ wb;
+        if (x) {
+            const int sh = (int)__builtin_ctzll(x) & ~7;
+            o += sh >> 3;
+            b_less = ((wb >> sh) & 0xFFull) < ((wa >> sh) & 0xFFull);
+            break;
+        }
+        o += 8;
+    }
+    return o < lim ? o : lim;
+}
+
 // Binary search of pat[0:maxLen) among the dictionary suffixes.  Invariant: suffix(lo) < pat <= suffix(hi); rank 0 is
 // the sentinel, rank n+1 is virtual.  Narrows [lo, hi] until hi == lo + 1; hi is then the lower bound of pat.
-// pk / prl: run_key of the pattern and the run length it vouches for.
+// pk / prl: run_key of the pattern and the run length it vouches for.  elo / ehi: the exact lcp(pat, suffix(lo / hi))
+// when the text compare of a probe with an equal key has produced it, else -1 (ends with a different key get
+// theirs from the keys, dict_lcp) - so the final step does not repeat the compares of the search.
 template <class KeyAt, class SaAt>
 __device__ inline void dict_search_in(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int &lo, int &hi,
-                                      KeyAt key_at, SaAt sa_at) {
-    int llo = 0, lhi = 0;  // lower bounds of lcp(pat, suffix(lo)) / lcp(pat, suffix(hi)) from text compares
+                                      int &elo, int &ehi, KeyAt key_at, SaAt sa_at) {
+    elo = -1;
+    ehi = -1;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         const uint64_t kq = key_at(mid);
         bool suffix_less;
-        int o = 0;
+        int o = -1;
         DS(2, 1)
         if (kq != pk) {
             suffix_less = kq < pk;  // the key order is the string order
@@ -263,20 +288,22 @@ __device__ inline void dict_search_in(const DictView &D, const uint8_t *pat, int
             const int q = sa_at(mid);
             const int avail = (int)D.n - q;
             const int lim = maxLen < avail ? maxLen : avail;
-            o = llo < lhi ? llo : lhi;
+            o = elo < ehi ? elo : ehi;  // both ends share that much with pat, so everything between does
             const int o1 = prl < lim ? prl : lim;
             DS(3, 1) DS(4, -(o > o1 ? o : o1))
-            o = lcp_bytes(pat, D.T + q, o > o1 ? o : o1, lim);
+            bool b_less;
+            o = lcp_cmp(pat, D.T + q, o > o1 ? o : o1, lim, b_less);
             DS(4, o + 8)
             if (o == maxLen) suffix_less = false;          // pat is a prefix of the suffix
             else if (o == avail) suffix_less = true;       // the suffix is a proper prefix of pat
-            else suffix_less = D.T[q + o] < pat[o];
+            else suffix_less = b_less;
         }
-        if (suffix_less) { lo = mid; llo = o; } else { hi = mid; lhi = o; }
+        if (suffix_less) { lo = mid; elo = o; } else { hi = mid; ehi = o; }
     }
 }
-__device__ inline void dict_search(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int &lo, int &hi) {
-    dict_search_in(D, pat, maxLen, pk, prl, lo, hi, [&](int k) { return D.key[k]; }, [&](int k) { return D.SA[k]; });
+__device__ inline void dict_search(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int &lo, int &hi,
+                                   int &elo, int &ehi) {
+    dict_search_in(D, pat, maxLen, pk, prl, lo, hi, elo, ehi, [&](int k) { return D.key[k]; }, [&](int k) { return D.SA[k]; });
 }
 
 // the bracket of every suffix sharing two bytes with pat; false if there is none
@@ -314,15 +341,16 @@ __device__ inline void dict_lookup(const DictView &D, const uint8_t *pat, int ma
     }
     DS(10, hi - lo)
     MP(12)
-    dict_search(D, pat, maxLen, pk, prl, lo, hi);
+    int elo, ehi;
+    dict_search(D, pat, maxLen, pk, prl, lo, hi, elo, ehi);
     MP(13)
     // hi == lo + 1: the suffix-array entries and the keys of both ends come with one load each
     int q2[2];
     uint64_t k2[2];
     __builtin_memcpy(q2, D.SA + lo, 8);
     __builtin_memcpy(k2, D.key + lo, 16);
-    const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo, q2[0], k2[0]);
-    const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi, q2[1], k2[1]);
+    const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo, q2[0], k2[0], elo);
+    const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi, q2[1], k2[1], ehi);
     Ld = llo > lhi ? llo : lhi;
     MP(14)
     DS(9, Ld)
@@ -342,7 +370,8 @@ __device__ inline int dict_lower_bound(const DictView &D, const uint8_t *pat, in
             hi = hi < se.y ? hi : se.y;
         }
     }
-    dict_search(D, pat, maxLen, pk, prl, lo, hi);
+    int elo, ehi;
+    dict_search(D, pat, maxLen, pk, prl, lo, hi, elo, ehi);
     return hi;
 }
 
@@ -377,21 +406,21 @@ __device__ inline void dict_lookup_wave(const DictView &D, const uint64_t *s_key
     if (!need) return;
     int prl = 0;
     const uint64_t pk = run_key_w(pat, maxLen, prl, run, w0);
-    int lo = LB, hi = hL;
+    int lo = LB, hi = hL, elo, ehi;
     int q2[2];
     uint64_t k2[2];
     if (staged) {
-        dict_search_in(D, pat, maxLen, pk, prl, lo, hi, [&](int k) { return s_key[k - LB]; }, [&](int k) { return s_dsa[k - LB]; });
+        dict_search_in(D, pat, maxLen, pk, prl, lo, hi, elo, ehi, [&](int k) { return s_key[k - LB]; }, [&](int k) { return s_dsa[k - LB]; });
         q2[0] = s_dsa[lo - LB]; q2[1] = s_dsa[lo - LB + 1];
         k2[0] = s_key[lo - LB]; k2[1] = s_key[lo - LB + 1];
     } else {
-        dict_search(D, pat, maxLen, pk, prl, lo, hi);
+        dict_search(D, pat, maxLen, pk, prl, lo, hi, elo, ehi);
         __builtin_memcpy(q2, D.SA + lo, 8);
         __builtin_memcpy(k2, D.key + lo, 16);
     }
     MP(13)
-    const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo, q2[0], k2[0]);
-    const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi, q2[1], k2[1]);
+    const int llo = dict_lcp(D, pat, maxLen, pk, prl, lo, q2[0], k2[0], elo);
+    const int lhi = dict_lcp(D, pat, maxLen, pk, prl, hi, q2[1], k2[1], ehi);
     Ld = llo > lhi ? llo : lhi;
     kd = lhi > llo ? hi : lo;
     MP(14)
@@ -476,6 +505,19 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     __shared__ uint64_t s_dkey[DICT_WIN + 2];  // the wave's bracket of the dictionary (dict_lookup_wave)
     __shared__ int32_t s_dsa[DICT_WIN + 2];
     const int wbase = (int)(bx * MATCH_THREADS) - WIN_HALO;
+    // the lane's own position comes straight from memory, so that the scattered reads that depend on it (below) are in
+    // flight while the windows are staged
+    bool work = r >= 1 && r < N;
+    int i = work ? SA[r] : 0;
+    work = work && !(i < (int)sg.start || i < HEAD);
+    // the lane's own scattered reads, issued together: the first 8 text bytes (reserved-symbol test, dictionary key)
+    // and the run lengths at i - 2 .. i + 1 (RLE skip test, dictionary key)
+    uint64_t w0 = 0;
+    uint32_t rl4 = 0;
+    if (work) {  // i >= HEAD > 2
+        w0 = ld8(T + i);
+        __builtin_memcpy(&rl4, ix.rlen + sg.off + i - 2, 4);
+    }
     for (int j = lane; j < WIN_TOTAL; j += 64) {
         int g = wbase + j;
         g = g < 0 ? 0 : (g > N + 3 ? N + 3 : g);  // LCP is zero at rank 0 and from N to N + 3: walks die there
@@ -498,20 +540,6 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
         }
     }
     __syncthreads();
-    bool work = r >= 1 && r < N;
-    int i = 0;
-    if (work) {
-        i = s_sa[WIN_HALO + lane];
-        work = !(i < (int)sg.start || i < HEAD);
-    }
-    // the lane's own scattered reads, issued together: the first 8 text bytes (reserved-symbol test, dictionary bucket
-    // and key) and the run lengths at i - 2 .. i + 1 (RLE skip test, dictionary key)
-    uint64_t w0 = 0;
-    uint32_t rl4 = 0;
-    if (work) {  // i >= HEAD > 2
-        w0 = ld8(T + i);
-        __builtin_memcpy(&rl4, ix.rlen + sg.off + i - 2, 4);
-    }
     // the walk can never call bestBackref(i) when i, i-1 and i-2 lie in one run of equal bytes and at least 160 of them
     // follow i: the RLE branch (compress.go:184) is taken at i, i-1 and i-2 (run lengths capped at 255)
     if (work && skip_unqueried && (rl4 & 0xFFu) >= LZSS_MIN_REPEAT + 2) {
