@@ -832,30 +832,71 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     //      blobs: the doubling rounds move 0.98 N suffixes in total instead of 2.44 N after a plain 4-symbol key).
     //      One sweep builds the records (key << 20 | suffix) in text order and counts the four digits.
     int32_t *hY = (int32_t *)L.act, *hX = hY + NB, *hC = L.hl, *hS = L.hh;  // act is free until the first regroup
-    for (uint32_t e0 = (uint32_t)w * 64; e0 < N; e0 += SAM_THREADS) {
-        const uint32_t e = e0 + lane;
-        const int rl = run_length_64(T, n, e, lane);
-        if (e < N) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
-        uint64_t rec = 0;
-        int dY = 0, dX = 0, dC = 0, dS = 0;
-        const bool valid = e < N;
-        if (valid) {
-            dS = e < n ? (int)T[e] + 1 : 0;
-            if (rl >= SA_RUN_CAP) {
-                dC = 255;
-            } else {
-                const uint32_t q = e + (uint32_t)rl;
-                dX = q < n ? (int)T[q] + 1 : 0;
-                dY = q + 1 < n ? (int)T[q + 1] + 1 : 0;
-                dC = dX < dS ? rl : 511 - rl;
+    {
+        // Every wave sweeps a contiguous range of 64-position blocks, so the "byte == next byte" ballots that give the
+        // run lengths slide: a block's run lengths read the flags of itself and the next four blocks (exact up to 257),
+        // and only the fifth is new in each step - one two-byte load per lane and step instead of ten byte loads.
+        const uint32_t nblk = (N + 63) / 64, per = (nblk + SAM_WAVES - 1) / SAM_WAVES;
+        const uint32_t bb = (uint32_t)w * per, be = bb + per < nblk ? bb + per : nblk;
+        auto eq_flags = [&](uint32_t blk) -> uint64_t {
+            const uint32_t q = blk * 64 + (uint32_t)lane;
+            bool eq = false;
+            if (q + 1 < n) {
+                uint16_t v;
+                __builtin_memcpy(&v, T + q, 2);
+                eq = (v & 0xFFu) == (v >> 8);
             }
-            rec = ((((((uint64_t)dS << 9) | (uint64_t)dC) << 9 | (uint64_t)dX) << 9 | (uint64_t)dY) << 20) | (uint64_t)e;
-            recB[e] = rec;
+            return __ballot(eq);
+        };
+        uint64_t E1 = 0, E2 = 0, E3 = 0, E4 = 0;
+        if (bb < be) {
+            E1 = eq_flags(bb);
+            E2 = eq_flags(bb + 1);
+            E3 = eq_flags(bb + 2);
+            E4 = eq_flags(bb + 3);
         }
-        digit_count(hY, dY, valid, lane);
-        digit_count(hX, dX, valid, lane);
-        digit_count(hC, dC, valid, lane);
-        digit_count(hS, dS, valid, lane);
+        for (uint32_t blk = bb; blk < be; ++blk) {
+            const uint64_t E0 = E1;
+            E1 = E2; E2 = E3; E3 = E4;
+            E4 = eq_flags(blk + 4);
+            const uint32_t e = blk * 64 + (uint32_t)lane;
+            // ones from this lane's flag on (run_length_64 on the sliding flags)
+            const uint64_t x0 = E0 >> lane;
+            int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);
+            if (rl == 64 - lane) {
+                const uint64_t Et[4] = {E1, E2, E3, E4};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rt = Et[t] == ~0ull ? 64 : (int)__builtin_ctzll(~Et[t]);
+                    rl += rt;
+                    if (rt < 64) break;
+                }
+            }
+            rl += 1;
+            const bool valid = e < N;
+            if (valid) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
+            uint64_t rec = 0;
+            int dY = 0, dX = 0, dC = 0, dS = 0;
+            if (valid) {
+                dS = e < n ? (int)T[e] + 1 : 0;
+                if (rl >= SA_RUN_CAP) {
+                    dC = 255;
+                } else {
+                    const uint32_t q = e + (uint32_t)rl;  // the two symbols after the run, one load (the text is zero padded)
+                    uint16_t v;
+                    __builtin_memcpy(&v, T + q, 2);
+                    dX = q < n ? (int)(v & 0xFFu) + 1 : 0;
+                    dY = q + 1 < n ? (int)(v >> 8) + 1 : 0;
+                    dC = dX < dS ? rl : 511 - rl;
+                }
+                rec = ((((((uint64_t)dS << 9) | (uint64_t)dC) << 9 | (uint64_t)dX) << 9 | (uint64_t)dY) << 20) | (uint64_t)e;
+                recB[e] = rec;
+            }
+            digit_count(hY, dY, valid, lane);
+            digit_count(hX, dX, valid, lane);
+            digit_count(hC, dC, valid, lane);
+            digit_count(hS, dS, valid, lane);
+        }
     }
     __syncthreads();
 
