@@ -27,6 +27,7 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
         agg[k]+=float(r['Counter_Value']); disp[k].add(r['Dispatch_Id'])
     for k in sorted(agg): rows.append((k,c,int(agg[k]),len(disp[k])))
 with open(f"{out}/{tag}_pmc_hbm_traffic.csv","w") as g:
+    g.write("# blobs=%s\n" % (sys.argv[3] if len(sys.argv) > 3 else "10000"))
     g.write("kernel,counter,sum_value_KB,dispatches\n")
     for r in rows: g.write("%s,%s,%d,%d\n"%r)
 print("ok", len(rows))
