@@ -3,14 +3,16 @@
 // Replaces Decompress (lzss/decompress.go:17-84) and backref.readFrom (lzss/backref.go:70-86) for a
 // batch of independent streams that share one dictionary.
 //
-// The phrase stream is bit-unaligned and strictly sequential (decompress.go:44-81), but two things
-// are wide inside one blob:
-//   * literals: from the current bit position every lane k extracts the byte at bit b + 8k; a ballot
-//     finds the first reserved symbol (0xFE / 0xFF) or the end of the stream, and all literals before
-//     it (a prefix count of the ballot mask) are stored at once at consecutive output positions;
-//   * back-references: the copy of up to 256 bytes is done by all lanes; an overlapping copy
-//     (offset < length: the run-length encodings of compress.go:175-218) is resolved in order by
-//     reading source byte (k mod offset), which only touches bytes written before this phrase.
+// The phrase stream is bit-unaligned and strictly sequential (decompress.go:44-81); what is wide inside one blob:
+//   * the stream is staged in LDS (2 KiB window, refilled with coalesced 16-byte loads), so the serial chain of a
+//     step is LDS latency, not a global round trip;
+//   * one step takes a literal run AND the back-reference behind it: every lane k extracts the byte at bit b + 8k, a
+//     ballot finds the first reserved symbol (0xFE / 0xFF) or the end of the stream, the literals before it (a
+//     prefix of the lanes) are stored at once, and the fields of the reference are the bytes of the next lanes
+//     (the same bit alignment), read with v_readlane - no further memory access to decode it;
+//   * the copy of up to 256 bytes is done by all lanes, four bytes per lane when source and destination do not
+//     overlap; an overlapping copy (offset < length: the run-length encodings of compress.go:175-218) is resolved in
+//     order by reading source byte (k mod offset), which only touches bytes written before this phrase.
 // Phrases are handled in stream order by the whole wave, so every copy sees its sources complete; a
 // workgroup-scope fence is issued only when a copy can reach bytes stored since the last fence.
 #include "kernels.h"
@@ -20,11 +22,22 @@ namespace lzss {
 constexpr int32_t ST_FORMAT = -6;    // MI355_LZSS_E_FORMAT
 constexpr int32_t ST_CAPACITY = -5;  // MI355_LZSS_E_CAPACITY
 
-__device__ inline uint64_t load_be64(const uint8_t *p) { return __builtin_bswap64(ld8(p)); }
+constexpr int DEC_WIN = 2048;        // bytes of the stream staged in LDS
+constexpr int DEC_NEED = 64 + 8;     // bytes one step may look at from its first byte on
+
+typedef uint32_t dec_u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ inline uint32_t ld4u(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ inline void st4u(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
 __global__ __launch_bounds__(64) void decompress_kernel(const uint8_t *in, const uint64_t *in_off, uint8_t *out,
                                                         const uint64_t *out_off, const uint8_t *dict, uint32_t dict_len,
                                                         uint32_t *out_len, int32_t *status) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_WIN + 16];
     const uint32_t blob = blockIdx.x;
     const int lane = threadIdx.x;
     const uint8_t *src = in + in_off[blob];
@@ -48,65 +61,99 @@ __global__ __launch_bounds__(64) void decompress_kernel(const uint8_t *in, const
         return;
     }
 
-    const uint64_t total = n * 8;        // bits in the stream (the input buffer is readable 16 bytes past n)
-    uint64_t b = LZSS_HEADER_SIZE * 8;   // current bit position (wave-uniform)
-    uint64_t opos = 0;                   // bytes produced so far (wave-uniform)
-    uint64_t unfenced = 0;               // bytes stored since the last fence
+    // The wave-uniform state lives on the scalar unit, which all waves of a CU share: with a whole batch resident that
+    // unit, not memory, bounds the kernel, so the state is 32 bits wide (a stream of MaxInputSize bytes has < 2^28
+    // bits; capacities are clamped) and the checks of a step are folded.
+    if (n >= (1ull << 28)) {
+        if (lane == 0) { status[blob] = ST_FORMAT; out_len[blob] = 0; }
+        return;
+    }
+    const uint32_t total = (uint32_t)n * 8u;   // bits in the stream (the input buffer is readable 16 bytes past n)
+    const uint32_t cap32 = cap > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)cap;
+    uint32_t b = LZSS_HEADER_SIZE * 8;   // current bit position (wave-uniform)
+    uint32_t opos = 0;                   // bytes produced so far (wave-uniform)
+    uint32_t fenced = 0;                 // output position of the last fence: bytes from there on may not be visible yet
+    uint32_t wend = 0;                   // first stream byte past the LDS window (0: no window yet)
+    uint32_t wbase = 0;
     int32_t st = 0;
 
     for (;;) {
-        // ---- literals: the byte at bit b + 8k for every lane
-        const uint64_t bk = b + 8ull * (uint64_t)lane;
-        const bool valid = bk + 8 <= total;
-        uint32_t sym = 0;
-        if (valid) {
-            const uint8_t *p = src + (bk >> 3);
-            const uint32_t two = ((uint32_t)p[0] << 8) | p[1];
-            sym = (two >> (8 - (uint32_t)(bk & 7))) & 0xFFu;
+        // ---- the window must hold the bytes this step may look at
+        const uint32_t byte0 = b >> 3;
+        if (byte0 + DEC_NEED > wend) {
+            wbase = byte0 & ~15u;
+            wend = wbase + DEC_WIN;
+            for (int j = lane; j < DEC_WIN / 16; j += 64) {
+                const uint32_t o = wbase + 16u * (uint32_t)j;
+                dec_u32x4_t v = {0u, 0u, 0u, 0u};
+                if (o <= (uint32_t)n) {
+                    typedef dec_u32x4_t unaligned_t __attribute__((aligned(1)));
+                    v = *reinterpret_cast<const unaligned_t *>(src + o);
+                }
+                *reinterpret_cast<dec_u32x4_t *>(s_in + 16 * j) = v;
+            }
+            __syncthreads();
         }
+        // ---- the byte at bit b + 8k for every lane
+        const uint32_t bk = b + 8u * (uint32_t)lane;
+        const bool valid = bk + 8 <= total;
+        const uint32_t bi = (bk >> 3) - wbase;
+        const uint32_t sh = 8u - (b & 7u);
+        const uint32_t two = ((uint32_t)s_in[bi] << 8) | (uint32_t)s_in[bi + 1];
+        // (also for lanes whose eight bits end past the stream: a reference at the very end needs 30 / 37 bits, not
+        // whole bytes, so its last field byte may come from such a lane; the bits past the stream are shifted out)
+        const uint32_t sym = (two >> sh) & 0xFFu;
         const bool stop = !valid || sym >= LZSS_SYMBOL_SHORT;
         const uint64_t mask = __ballot(stop);
-        const int f = mask ? (int)__builtin_ctzll(mask) : 64;  // number of literals in front of the stop
-        if (opos + (uint64_t)f > cap) { st = ST_CAPACITY; break; }
-        if (lane < f) dst[opos + (uint64_t)lane] = (uint8_t)sym;
-        opos += (uint64_t)f;
-        unfenced += (uint64_t)f;
-        b += 8ull * (uint64_t)f;
-        if (f == 64) continue;
-        const uint32_t symf = (uint32_t)__shfl((int)sym, f);
-        const bool validf = (__ballot(valid) >> f) & 1ull;
-        if (!validf) break;  // fewer than 8 bits left: the reader's EOF ends the loop (decompress.go:45)
+        const uint32_t f = mask ? (uint32_t)__builtin_ctzll(mask) : 64u;  // number of literals in front of the stop
+        if (opos + f > cap32) { st = ST_CAPACITY; break; }
+        if ((uint32_t)lane < f) dst[opos + (uint32_t)lane] = (uint8_t)sym;
+        opos += f;
+        b += 8u * f;
+        if (f > 59) continue;                 // all literals, or the fields of the reference are not all in this step's lanes
+        if (b + 8 > total) break;             // fewer than 8 bits left: the reader's EOF ends the loop (decompress.go:45)
 
-        // ---- back-reference at bit b (backref.go:70-86): delimiter(8) | length-1 (8) | offset-1 (14 | 21)
-        const bool is_short = symf == LZSS_SYMBOL_SHORT;
-        const int nb = is_short ? LZSS_SHORT_BITS : LZSS_DYN_BITS;
-        if (b + (uint64_t)nb > total) { st = ST_FORMAT; break; }  // truncated reference: readFrom returns the EOF
-        const uint64_t v = load_be64(src + (b >> 3)) << (b & 7);
-        const uint64_t field = v >> (64 - nb);
-        const int abits = is_short ? LZSS_SHORT_ADDR_BITS : LZSS_DYN_ADDR_BITS;
-        const uint32_t len = (uint32_t)((field >> abits) & 0xFFu) + 1;
-        const uint64_t off = (field & ((1ull << abits) - 1)) + 1;
-        if (opos + len > cap) { st = ST_CAPACITY; break; }
+        // ---- back-reference at bit b (backref.go:70-86): delimiter(8) | length-1 (8) | offset-1 (14 | 21); its bytes
+        //      are the symbols of lanes f .. f + 4
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)sym, (int)f);
+        const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)sym, (int)f + 1);
+        const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)sym, (int)f + 2);
+        const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane((int)sym, (int)f + 3);
+        const uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)sym, (int)f + 4);
+        const bool is_short = s0 == LZSS_SYMBOL_SHORT;
+        const uint32_t nb = is_short ? LZSS_SHORT_BITS : LZSS_DYN_BITS;
+        const uint32_t len = s1 + 1;
+        const uint32_t off = (is_short ? ((s2 << 6) | (s3 >> 2)) : ((s2 << 13) | (s3 << 5) | (s4 >> 3))) + 1;
+        if (b + nb > total) { st = ST_FORMAT; break; }  // truncated reference: readFrom returns the EOF
+        if (opos + len > cap32) { st = ST_CAPACITY; break; }
+        uint8_t *d0 = dst + opos;
+        const uint32_t k4 = 4u * (uint32_t)lane;
         if (off > opos) {
-            if (is_short) { st = ST_FORMAT; break; }  // decompress.go:53-55
-            // the reference starts in the dictionary and must end there (decompress.go:65-70)
-            const int64_t dict_start = (int64_t)dict_len - (int64_t)(off - opos);
-            if (dict_start < 0 || dict_start + (int64_t)len > (int64_t)dict_len) { st = ST_FORMAT; break; }
-            for (uint32_t k = lane; k < len; k += 64) dst[opos + k] = dict[dict_start + k];
+            // the reference starts in the dictionary and must end there (decompress.go:65-70); a short one cannot (:53-55)
+            const uint32_t back = off - opos;  // bytes before the end of the dictionary
+            if (is_short || back > dict_len || len > back) { st = ST_FORMAT; break; }
+            const uint8_t *sp = dict + (dict_len - back);
+            if (k4 + 4 <= len) st4u(d0 + k4, ld4u(sp + k4));
+            else
+                for (uint32_t t = k4; t < len; ++t) d0[t] = sp[t];
         } else {
-            const uint64_t span = off < len ? off : len;  // the copy reads [opos - off, opos - off + span)
-            if (unfenced > off - span) {  // ... which reaches bytes this wave stored after its last fence
+            const uint32_t span = off < len ? off : len;  // the copy reads [opos - off, opos - off + span)
+            if (opos - off + span > fenced) {  // ... which reaches bytes this wave stored after its last fence
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                unfenced = 0;
+                fenced = opos;
             }
-            const uint8_t *s0 = dst + (opos - off);
-            const uint32_t o32 = (uint32_t)off;
-            for (uint32_t k = lane; k < len; k += 64) dst[opos + k] = s0[off >= len ? k : k % o32];
+            const uint8_t *sp = d0 - off;
+            if (off >= len) {  // source and destination apart: four bytes per lane
+                if (k4 + 4 <= len) st4u(d0 + k4, ld4u(sp + k4));
+                else
+                    for (uint32_t t = k4; t < len; ++t) d0[t] = sp[t];
+            } else {
+                for (uint32_t k = lane; k < len; k += 64) d0[k] = sp[k % off];
+            }
         }
         opos += len;
-        unfenced += len;
-        b += (uint64_t)nb;
+        b += nb;
     }
     if (lane == 0) {
         status[blob] = st;
