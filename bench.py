@@ -39,33 +39,45 @@ def pmc_traffic(stage, n_blobs):
     """HBM bytes per launch of the stage's kernel from the COMMITTED rocprofv3 --pmc passes of this same command
     (scripts/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate runs with --overlap 1, KB -> bytes) - a
     profile of the committed kernels, not a measurement of the run that prints it (PMC passes cannot run inside
-    the bench).  FETCH_SIZE is left uncorrected: the guide's x2 applies to wide coalesced streams; the factors for
-    this path's access widths were measured with scripts/calib_fetch.sh (profiles/*_fetch_calibration.txt).  The
-    number of batch launches in the profiled run is the dispatch count of match_kernel (the dictionary's
-    one-segment launches at context creation add < 0.1 % to the other kernels' sums)."""
+    the bench).  Returns (traffic, fetch_reported, write, source) with traffic = WRITE_SIZE + 2 x FETCH_SIZE: on gfx950
+    FETCH_SIZE reports half the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM); scripts/calib_fetch.sh
+    (profiles/r02_fetch_calibration.txt) measured that factor 0.500 for 1-, 4-, 8- and 16-byte-per-lane streams alike, 1.0
+    per 64-byte line for scattered 4-byte gathers and 1.0-1.05 for WRITE_SIZE - the kernels here mix streams and gathers,
+    so the doubled figure is an upper bound (by at most the gathers' share).  Launches of the whole batch in the profiled
+    run: the file's "# batch_launches=" note (the one-blob and dictionary launches add < 0.1 % to the sums)."""
+    none = (None, None, None, None)
     if PMC_FILE is None:
-        return None, None
+        return none
     path = os.path.join(ROOT, "profiles", PMC_FILE)
     kernel = {"sa_build": "lzss::sa_build_kernel", "match": "lzss::match_kernel", "lcp": "lzss::lcp_kernel"}.get(stage)
     if kernel is None or not os.path.exists(path):
-        return None, None
+        return none
     lines = open(path).read().splitlines()
     profiled_blobs = 1250   # round-1 profiles carry no note; later ones start with "# blobs=N"
-    if lines and lines[0].startswith("# blobs="):
-        profiled_blobs = int(lines[0].split("=")[1])
+    batch_launches = None
+    while lines and lines[0].startswith("#"):
+        k_, v_ = lines[0][1:].strip().split("=")
+        if k_ == "blobs":
+            profiled_blobs = int(v_)
+        elif k_ == "batch_launches":   # launches of the whole batch in the profiled run (the rest are one-blob launches)
+            batch_launches = int(v_)
         lines = lines[1:]
     if n_blobs != profiled_blobs:
-        return None, None
-    total, launches = 0.0, 1
+        return none
+    fetch, write, launches = 0.0, 0.0, 1
     for line in lines[1:]:
         k, c, v, nd = line.rsplit(",", 3)
         k = k.replace("void ", "").split("<")[0]
-        if k == kernel:
-            total += float(v) * 1024.0
+        if k == kernel and c == "FETCH_SIZE":
+            fetch += float(v) * 1024.0
+        if k == kernel and c == "WRITE_SIZE":
+            write += float(v) * 1024.0
         if k == "lzss::match_kernel" and c == "FETCH_SIZE":
             launches = max(1, int(nd))
-    return int(total / launches), ("committed profile profiles/%s (rocprofv3 --pmc, FETCH_SIZE + WRITE_SIZE, per launch; "
-                                   "not measured in this run)" % PMC_FILE)
+    launches = batch_launches or launches
+    return (int((2.0 * fetch + write) / launches), int(fetch / launches), int(write / launches),
+            "committed profile profiles/%s (rocprofv3 --pmc, WRITE_SIZE + 2 x FETCH_SIZE per launch of the whole batch; "
+            "not measured in this run)" % PMC_FILE)
 
 
 def main():
@@ -79,6 +91,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming (config 4) sample")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-blob (config 2) latency sample")
     ap.add_argument("--overlap", type=int, default=2, help="concurrent sub-batches of the index / match stages")
     ap.add_argument("--stage-steps", type=int, default=2, help="extra untimed steps (one part) for the per-kernel times")
     ap.add_argument("--pipe-repeats", type=int, default=1, help="the batch repeated this many times through the "
@@ -227,7 +240,7 @@ def main():
         # algorithmic bytes of one launch: sum(n_in + n_out) + n_dict
         alg_bytes = in_bytes + int(out_total) + len(compress_amd.AugmentDict(dict_))
         achieved = alg_bytes / (stages[dom] * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom, len(blobs))
+        traffic, fetch_rep, write_rep, traffic_src = pmc_traffic(dom, len(blobs))
         line = {
             "metric": "compress MB/s (whole node, bit-exact) + % HBM roofline at 1/2/4/8 GPUs",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -238,7 +251,8 @@ def main():
                        "dict_bytes": len(dict_), "ratio": round(in_bytes / max(1, int(out_total)), 3),
                        "overlap_parts": parts},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_fetch_size_reported": fetch_rep,
+                         "traffic_write_size": write_rep, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stages[dom], 3)},
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "stages_note": "HIP-event time of every stage with the stages back to back (overlap 1), measured on extra "
@@ -252,7 +266,7 @@ def main():
             "serial_upload_compress_download_MBps": round(in_bytes / (t_up + elapsed / args.steps + t_down) / 1e6, 2),
         }
         # ---- config 2: latency of ONE 128 KiB blob with the 64 KiB dictionary through Compress (host buffers in and out)
-        if world == 1:
+        if world == 1 and not args.no_latency:
             comp1 = compress_amd.Compressor(dict_, device=local_rank)
             comp1.Compress(blobs[0])
             lat = []

@@ -1,0 +1,42 @@
+#!/bin/bash
+# usage (GPU box): scripts/sq_counters.sh TAG [BLOBS] -> gpurun_out/TAG_sq_counters.csv
+# Per-kernel SQ / TA counters of one bench step (kernels serialized), one rocprofv3 --pmc run per counter group
+# (at most 8 SQ and 2 TA counters per run).  Values are per launch, summed over the chip's shader engines;
+# SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants).
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out
+tag=$1
+blobs=${2:-1250}
+cd /tmp && export TMPDIR=/tmp
+groups=(
+ "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"
+ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"
+ "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
+ "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE"
+)
+g=0
+for grp in "${groups[@]}"; do
+  rm -rf $out/${tag}_sq_$g
+  timeout -s KILL 150 rocprofv3 --pmc $grp -d $out/${tag}_sq_$g -o p --output-format csv -- python3 $root/bench.py --blobs $blobs --steps 1 --warmup 1 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-repeats 0 > $out/${tag}_sq_$g.log 2>&1
+  rc=$?
+  if [ $rc -ne 0 ]; then echo "group $g ($grp) failed rc=$rc"; tail -3 $out/${tag}_sq_$g.log; if [ $rc -ge 124 ]; then exit 1; fi; fi
+  g=$((g+1))
+done
+python3 - "$out" "$tag" "$blobs" <<'PY'
+import sys,csv,glob,collections,re
+out,tag,blobs=sys.argv[1:4]
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter(); names=[]
+for f in sorted(glob.glob(f"{out}/{tag}_sq_*/**/*counter_collection.csv",recursive=True)):
+    for r in csv.DictReader(open(f)):
+        k=re.sub(r"\(.*","",r['Kernel_Name']).replace("void ","")
+        c=r['Counter_Name']
+        if c not in names: names.append(c)
+        agg[k][c]+=float(r['Counter_Value']); cnt[(k,c)]+=1
+with open(f"{out}/{tag}_sq_counters.csv","w") as g:
+    g.write(f"# blobs={blobs}; per launch (mean over the launches of one warm-up + one timed step); rocprofv3 --pmc, one run per group\n")
+    g.write("kernel,"+",".join(names)+"\n")
+    for k in sorted(agg):
+        if not k.startswith("lzss::"): continue
+        g.write(k+","+",".join(("%.6g"%(agg[k][c]/cnt[(k,c)]) if cnt[(k,c)] else "") for c in names)+"\n")
+print(open(f"{out}/{tag}_sq_counters.csv").read())
+PY
