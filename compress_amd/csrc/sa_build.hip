@@ -442,13 +442,15 @@ struct SaLds {
     static constexpr int mtab_entries() { return 1 << (DB < MTB ? DB : MTB); }
     uint32_t *act;     // bit p: suffix p still shares its group
     int32_t *base;     // [NB] running output index of bin b
-    int32_t *delta;    // [NB] output index minus staging index for the tile's entries of bin b
-    int32_t *tpos;     // [NB] staging index of the tile's first entry of bin b
+    int32_t *delta;    // [NB] output index of the current tile's first entry of bin b
+    int32_t *tpos;     // [NB] scratch: digit counts of a late round's second keys (low digit)
     int32_t *hl, *hh;  // [NB] digit counts of the next round's keys (low / high digit)
     int32_t *hy;       // [NB] digit counts of a late round's second keys (high digit; the low digit's sit in tpos)
     int32_t *wtot;     // [16] tile entries per wave of bin threads
-    uint16_t *whist;   // [NB][SAM_WAVES] entries of the current tile per bin and wave (zero between tiles)
-    uint16_t *woff;    // [NB][SAM_WAVES] offset of wave w's entries inside the tile's bin b
+    uint16_t *whist;   // [SAM_WAVES / 2][NB][2] entries of the current tile per bin and wave (zero between tiles): waves
+                       // 2k and 2k + 1 share a 32-bit word, a row holds the NB bins, so a wave's lanes with different
+                       // digits reach different banks (a [NB][SAM_WAVES] layout put them 16 bytes apart: 16 banks only)
+    uint16_t *woff;    // the same layout: offset of wave w's entries inside the tile's bin b
     uint64_t *mtab;    // [SAM_WAVES][mtab_entries()] per wave: lanes holding (the low bits of) digit d (zero between steps)
     __device__ SaLds(uint32_t *mem, uint32_t words) {
         act = mem;
@@ -463,6 +465,7 @@ struct SaLds {
         woff = whist + SAM_WAVES * NB;
         mtab = (uint64_t *)(woff + SAM_WAVES * NB);
     }
+    static __device__ inline int cell(int d, int w) { return ((((w >> 1) * NB) + d) << 1) | (w & 1); }
     // words: bitmap words (even)
     static size_t bytes(uint32_t words) {
         return (size_t)words * 4 + ((size_t)NB * 6 + 16) * 4 + (size_t)SAM_WAVES * NB * 4 +
@@ -520,7 +523,7 @@ __device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lan
 // rank of this lane's entry among the entries of its wave's tile part with the same digit (stable)
 template <int RB, int DB>
 __device__ inline int tile_rank(const SaLds<DB> &L, int w, int d, bool valid, int lane) {
-    uint16_t *cell = L.whist + d * SAM_WAVES + w;
+    uint16_t *cell = L.whist + SaLds<DB>::cell(d, w);
     const uint64_t peers = wave_peers<RB, SaLds<DB>::MTB>(L.mtab + w * SaLds<DB>::mtab_entries(), d, valid, lane);
     const int cnt = __popcll(peers);
     const int rank = __popcll(peers & lanemask_lt(lane));
@@ -531,73 +534,44 @@ __device__ inline int tile_rank(const SaLds<DB> &L, int w, int d, bool valid, in
     return lh + rank;
 }
 
-// After every wave has ranked its part of the tile: per-wave counts -> offsets inside the tile's bins, bins ->
-// staging positions (a scan over the bins) and output positions (the running bases advance).  Three barriers.
-// Returns the number of entries of the tile.
+// After every wave has ranked its part of the tile: per-wave counts -> offsets inside the tile's bins, and every bin's
+// output position for this tile (the running bases advance).  Two barriers.
 template <int DB>
-__device__ inline int tile_prepare(const SaLds<DB> &L, int tid) {
+__device__ inline void tile_prepare(const SaLds<DB> &L, int tid) {
     constexpr int NB = 1 << DB;
     constexpr int BPT = NB > SAM_THREADS ? NB / SAM_THREADS : 1;  // consecutive bins per bin thread
     constexpr int NBT = NB / BPT;
-    const int lane = tid & 63, w = tid >> 6;
     __syncthreads();
-    int run[BPT], gs[BPT];
-    int tot = 0;
-#pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-        run[i] = 0;
-        gs[i] = 0;
-        if (tid < NBT) {
-            const int b = tid * BPT + i;
-            // the bin's counts of all waves in one load, their running sums in one store
-            typedef uint16_t u16xw_t __attribute__((ext_vector_type(SAM_WAVES)));
-            u16xw_t *hp = reinterpret_cast<u16xw_t *>(L.whist + b * SAM_WAVES);
-            const u16xw_t cnts = *hp;
-            u16xw_t offs;
-            int r = 0;
-#pragma unroll
-            for (int ww = 0; ww < SAM_WAVES; ++ww) {
-                offs[ww] = (uint16_t)r;
-                r += (int)cnts[ww];
-            }
-            *hp = (u16xw_t)(uint16_t)0;
-            *reinterpret_cast<u16xw_t *>(L.woff + b * SAM_WAVES) = offs;
-            run[i] = r;
-            gs[i] = L.base[b];
-            L.base[b] = gs[i] + r;
-            tot += r;
-        }
-    }
-    const int inc = wave_incl_add(tot, lane);
-    if (lane == 63) L.wtot[w] = inc;
-    __syncthreads();
-    int carry = 0, total = 0;
-#pragma unroll
-    for (int ww = 0; ww < SAM_WAVES; ++ww) {
-        const int t = L.wtot[ww];
-        if (ww < w) carry += t;
-        total += t;
-    }
     if (tid < NBT) {
-        int pre = carry + inc - tot;
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const int b = tid * BPT + i;
-            L.tpos[b] = pre;
-            L.delta[b] = gs[i] - pre;
-            pre += run[i];
+            // the bin's counts of two waves per load, their running sums likewise
+            uint32_t *hp = reinterpret_cast<uint32_t *>(L.whist) + b;
+            uint32_t *op = reinterpret_cast<uint32_t *>(L.woff) + b;
+            int r = 0;
+#pragma unroll
+            for (int wp = 0; wp < SAM_WAVES / 2; ++wp) {
+                const uint32_t c2 = hp[wp * NB];
+                const uint32_t o2 = (uint32_t)r | ((uint32_t)(r + (int)(c2 & 0xFFFFu)) << 16);
+                r += (int)(c2 & 0xFFFFu) + (int)(c2 >> 16);
+                hp[wp * NB] = 0u;
+                op[wp * NB] = o2;
+            }
+            const int gs = L.base[b];
+            L.delta[b] = gs;
+            L.base[b] = gs + r;
         }
     }
     __syncthreads();
-    return total;
 }
 
-// one record of the tile to its place in the output: the running base of its bin + the records of the bin that
-// precede it in the tile (delta + tpos is that base; tpos alone would be its place in a tile sorted in LDS - staging
-// tiles that way so that the scatter writes whole runs was measured without gain and removed)
+// one record of the tile to its place in the output: the running base of its bin (delta) + the records of the bin that
+// precede it in the tile (staging tiles sorted in LDS so that the scatter writes whole runs was measured without gain
+// and removed)
 template <int DB>
 __device__ inline void tile_put(const SaLds<DB> &L, uint64_t *out, int d, int w, int loc, uint64_t r) {
-    out[L.delta[d] + L.tpos[d] + (int)L.woff[d * SAM_WAVES + w] + loc] = r;
+    out[L.delta[d] + (int)L.woff[SaLds<DB>::cell(d, w)] + loc] = r;
 }
 
 // histogram update of one 64-entry step: two leader votes take the most frequent digits, the rest adds itself
