@@ -568,14 +568,24 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
             qupS = min3u(qupS, min3u(cS[0], cS[1], cS[2]), cS[3]);
             qupL = min3u(qupL, min3u(cL[0], cL[1], cL[2]), cL[3]);
             done = done || m < minS || qupS != NONE_UP || k + 4 >= N;
+            // a long-window hit of a useful length ends the search for a short-window hit as soon as the running lcp has
+            // dropped below it: the short window lies inside the long one, and a short reference only wins with
+            // Ls >= LL (compress.go:165), so a shorter short-window match on this side can never be selected
+            const int lf = qupL != NONE_UP ? (int)(qupL & 511u) : 0;
+            done = done || (lf >= minD && m < lf);
             k = done ? k : k + 4;
         }
         MP(1)
         for (uint64_t hm = (ablate & 16) ? 0ull : __ballot(!done); hm; hm &= hm - 1) {  // the wave finishes lane t's walk
             const int t = (int)__builtin_ctzll(hm);
-            const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
+            const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cminD = __shfl(minD, t);
+            int cmin = __shfl(minS, t);  // the lcp below which the walk ends; raised by a useful long-window hit (see above)
             int cm = __shfl(m, t);
             bool cfL = __shfl((int)(qupL != NONE_UP), t) != 0;
+            {
+                const int lv = __shfl((int)(qupL & 511u), t);
+                if (cfL && lv >= cminD && lv > cmin) cmin = lv;
+            }
             uint32_t rL = NONE_UP, rS = NONE_UP;
             DS(11, 1)
             for (int base = __shfl(k, t); base < N; base += 64) {
@@ -586,15 +596,19 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
                 const int p = valid ? SA[kk] : 0x7FFFFFFF;
                 int pm = wave_incl_min(l, lane);
                 pm = pm < cm ? pm : cm;
+                if (!cfL) {
+                    const uint64_t bL = __ballot(pm >= cmin && p < ci && p >= cwl);
+                    if (bL) {
+                        const int t2 = (int)__builtin_ctzll(bL);
+                        const int lv = __shfl(pm, t2);
+                        rL = ((uint32_t)(base + t2) << 9) | (uint32_t)lv;
+                        cfL = true;
+                        if (lv >= cminD && lv > cmin) cmin = lv;
+                    }
+                }
                 const bool alive = pm >= cmin;
-                const uint64_t bL = __ballot(alive && p < ci && p >= cwl);
                 const uint64_t bS = __ballot(alive && p < ci && p >= cws);
                 const uint64_t bDead = __ballot(!alive);
-                if (!cfL && bL) {
-                    const int t2 = (int)__builtin_ctzll(bL);
-                    rL = ((uint32_t)(base + t2) << 9) | (uint32_t)__shfl(pm, t2);
-                    cfL = true;
-                }
                 if (bS) {
                     const int t2 = (int)__builtin_ctzll(bS);
                     rS = ((uint32_t)(base + t2) << 9) | (uint32_t)__shfl(pm, t2);
@@ -614,6 +628,10 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
     {
         int m = 1 << 20, k = r - 1;
         bool done = !scan;
+        // the same bound from the other side: a useful long-window match above r makes every shorter match below r
+        // irrelevant in both windows (LL is the larger of the two sides, and Ls must reach LL to be selected)
+        const int upL0 = qupL != NONE_UP ? (int)(qupL & 511u) : 0;
+        const int floor0 = (upL0 >= minD && upL0 > minS) ? upL0 : minS;
         for (int it = 0; it < SCAN_CAP && __ballot(!done && k >= 4); ++it) {  // ranks k, k-1, k-2, k-3
             const bool go = !done && k >= 4;
             const int j = go ? k - 3 - wbase : WIN_TOTAL;  // rank kk's lcp with its upper neighbour is LCP[kk + 1]
@@ -629,7 +647,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
             }
             qdnS = max3u(qdnS, max3u(cS[0], cS[1], cS[2]), cS[3]);
             qdnL = max3u(qdnL, max3u(cL[0], cL[1], cL[2]), cL[3]);
-            const bool stop = m < minS || qdnS != NONE_DN;
+            const int lf = (int)(qdnL & 511u);  // 0 while there is no long-window hit on this side
+            const bool stop = m < floor0 || qdnS != NONE_DN || (lf >= minD && m < lf);
             done = done || (go && stop);
             k = (go && !stop) ? k - 4 : k;
         }
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
             for (; k >= 1; --k) {
                 const int l = LCP[k + 1];
                 m = l < m ? l : m;
-                if (m < minS) break;
+                if (m < floor0) break;
                 const int p = SA[k];
                 if (p < i) {
                     const uint32_t key = ((uint32_t)k << 9) | (uint32_t)m;
@@ -650,9 +669,14 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
         MP(3)
         for (uint64_t hm = (ablate & 16) ? 0ull : __ballot(!done); hm; hm &= hm - 1) {
             const int t = (int)__builtin_ctzll(hm);
-            const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cmin = __shfl(minS, t);
+            const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cminD = __shfl(minD, t);
+            int cmin = __shfl(floor0, t);
             int cm = __shfl(m, t);
             bool cfL = __shfl((int)(qdnL != NONE_DN), t) != 0;
+            {
+                const int lv = __shfl((int)(qdnL & 511u), t);
+                if (cfL && lv >= cminD && lv > cmin) cmin = lv;
+            }
             uint32_t rL = NONE_DN, rS = NONE_DN;
             DS(13, 1)
             for (int base = __shfl(k, t); base >= 1; base -= 64) {
@@ -663,15 +687,19 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
                 const int p = valid ? SA[kk] : 0x7FFFFFFF;
                 int pm = wave_incl_min(l, lane);
                 pm = pm < cm ? pm : cm;
+                if (!cfL) {
+                    const uint64_t bL = __ballot(pm >= cmin && p < ci && p >= cwl);
+                    if (bL) {
+                        const int t2 = (int)__builtin_ctzll(bL);
+                        const int lv = __shfl(pm, t2);
+                        rL = ((uint32_t)(base - t2) << 9) | (uint32_t)lv;
+                        cfL = true;
+                        if (lv >= cminD && lv > cmin) cmin = lv;
+                    }
+                }
                 const bool alive = pm >= cmin;
-                const uint64_t bL = __ballot(alive && p < ci && p >= cwl);
                 const uint64_t bS = __ballot(alive && p < ci && p >= cws);
                 const uint64_t bDead = __ballot(!alive);
-                if (!cfL && bL) {
-                    const int t2 = (int)__builtin_ctzll(bL);
-                    rL = ((uint32_t)(base - t2) << 9) | (uint32_t)__shfl(pm, t2);
-                    cfL = true;
-                }
                 if (bS) {
                     const int t2 = (int)__builtin_ctzll(bS);
                     rS = ((uint32_t)(base - t2) << 9) | (uint32_t)__shfl(pm, t2);

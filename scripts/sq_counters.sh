@@ -25,18 +25,24 @@ done
 python3 - "$out" "$tag" "$blobs" <<'PY'
 import sys,csv,glob,collections,re
 out,tag,blobs=sys.argv[1:4]
-agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter(); names=[]
+rows=collections.defaultdict(list); names=[]
 for f in sorted(glob.glob(f"{out}/{tag}_sq_*/**/*counter_collection.csv",recursive=True)):
     for r in csv.DictReader(open(f)):
         k=re.sub(r"\(.*","",r['Kernel_Name']).replace("void ","")
         c=r['Counter_Name']
         if c not in names: names.append(c)
-        agg[k][c]+=float(r['Counter_Value']); cnt[(k,c)]+=1
+        rows[(k,c)].append((int(r['Grid_Size']),float(r['Counter_Value'])))
+kernels=sorted({k for k,_ in rows if k.startswith("lzss::")})
 with open(f"{out}/{tag}_sq_counters.csv","w") as g:
-    g.write(f"# blobs={blobs}; per launch (mean over the launches of one warm-up + one timed step); rocprofv3 --pmc, one run per group\n")
-    g.write("kernel,"+",".join(names)+"\n")
-    for k in sorted(agg):
-        if not k.startswith("lzss::"): continue
-        g.write(k+","+",".join(("%.6g"%(agg[k][c]/cnt[(k,c)]) if cnt[(k,c)] else "") for c in names)+"\n")
+    g.write(f"# blobs={blobs}; per launch of the whole batch (the launches with the kernel's largest grid; the dictionary's and other one-segment launches are left out); rocprofv3 --pmc, one run per group\n")
+    g.write("kernel,batch_launches,"+",".join(names)+"\n")
+    for k in kernels:
+        vals=[]; nl=0
+        for c in names:
+            v=rows.get((k,c),[])
+            if not v: vals.append(""); continue
+            gm=max(x for x,_ in v); sel=[y for x,y in v if x==gm]; nl=len(sel)
+            vals.append("%.6g"%(sum(sel)/len(sel)))
+        g.write(k+","+str(nl)+","+",".join(vals)+"\n")
 print(open(f"{out}/{tag}_sq_counters.csv").read())
 PY
