@@ -126,6 +126,24 @@ __device__ inline int lcp_bytes(const uint8_t *a, const uint8_t *b, int from, in
     return o < lim ? o : lim;
 }
 
+// the same, 16 bytes per round trip (for compares that are expected to run a few words); both readable 16 bytes past lim
+__device__ inline int lcp_bytes16(const uint8_t *a, const uint8_t *b, int from, int lim) {
+    int o = from;
+    while (o < lim) {
+        const uint64_t x0 = ld8(a + o) ^ ld8(b + o), x1 = ld8(a + o + 8) ^ ld8(b + o + 8);
+        if (x0) {
+            o += (int)(__builtin_ctzll(x0) >> 3);
+            break;
+        }
+        if (x1) {
+            o += 8 + (int)(__builtin_ctzll(x1) >> 3);
+            break;
+        }
+        o += 16;
+    }
+    return o < lim ? o : lim;
+}
+
 // common prefix length of the suffixes at a and b (a != b), at most lim, with the run lengths RL of the text (length
 // of the run of equal bytes starting at every position, capped at 255): different run lengths settle the answer
 // without a text compare, equal ones let it start behind the run (long runs are what makes prefixes long here)
