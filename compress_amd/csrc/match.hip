@@ -74,10 +74,17 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint3
     int sak = INT_MAX;
     uint64_t wb = 0;
     int rb = 0;
+    // the run length at a suffix: read off its first 8 bytes when the run ends inside them (no scattered load of its own)
+    auto run_at = [&](int pos, uint64_t wd) -> int {
+        const uint64_t x = wd ^ ((wd & 0xFFull) * 0x0101010101010101ull);
+        if (x == 0) return (int)RL[pos];  // 8 equal bytes (or the zero padding): the suffix sort's count
+        const int r8 = (int)(__builtin_ctzll(x) >> 3), rest = (int)sg.n - pos;
+        return r8 < rest ? r8 : rest;     // a run of zeros must not continue into the padding
+    };
     if (k < N) {  // the sentinel's "text" is the zero padding
         sak = SA[k];
         wb = ld8(T + sak);
-        rb = RL[sak];
+        rb = run_at(sak, wb);
     }
     // the upper suffix of the pair is the neighbour lane's; the first lane of a wave fetches it
     int a = __shfl_up(sak, 1);
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint3
     if ((threadIdx.x & 63) == 0 && k > 0 && k < N) {
         a = SA[k - 1];
         wa = ld8(T + a);
-        ra = RL[a];
+        ra = run_at(a, wa);
     }
     if (k < N) {
         l = 0;
