@@ -106,11 +106,28 @@ __device__ inline int leftmost(const SegIndex &S, int kdn, int L, int ws, int i,
     MP(8)
     int res = -1;
     if (kdn - lo <= LINEAR_SPAN || (!is_short && ws != 0)) {
-        for (int k = lo; k < kdn && res < 0; ++k) {
-            const int p = S.SA[k];
-            if (p >= ws && p < i) res = p;
+        if (kdn - lo <= LINEAR_SPAN) {
+            // the whole interval in one round trip: all loads are issued before the first is looked at (rank kdn is
+            // inside the window, so the scan ends there at the latest)
+            constexpr int NQ = LINEAR_SPAN / 4 + 1;
+            I4 q[NQ];
+#pragma unroll
+            for (int t = 0; t < NQ; ++t)
+                if (lo + 4 * t <= kdn) q[t] = ld_i4(S.SA + lo + 4 * t);  // entries past kdn are ignored
+#pragma unroll
+            for (int t = 0; t < NQ; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = q[t].v[u];
+                    if (res < 0 && lo + 4 * t + u <= kdn && p >= ws && p < i) res = p;
+                }
+        } else {
+            for (int k = lo; k < kdn && res < 0; ++k) {
+                const int p = S.SA[k];
+                if (p >= ws && p < i) res = p;
+            }
+            if (res < 0) res = S.SA[kdn];
         }
-        if (res < 0) res = S.SA[kdn];
         MP(9)
     } else if (is_short) {
         int best = kdn;
