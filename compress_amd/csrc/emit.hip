@@ -31,40 +31,29 @@ __device__ inline int savings_of(uint32_t r) {  // backref.savings, lzss/backref
     return 8 * (int)res_len(r) - (t == RES_SHORT ? LZSS_SHORT_BITS : LZSS_DYN_BITS);
 }
 
-// One workgroup per 256-position tile.  After the phrase at every position is known, the tile also resolves, for
-// every position x, where the chain x -> x + advance(x) first lands past the tile and how many phrase bits it writes
-// on the way (pointer doubling in LDS: <= 8 rounds, fewer when every chain has left the tile) - what walk_kernel
-// needs to hop from tile to tile without ever walking inside one.
-__global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs, const uint8_t *text, const uint8_t *rlen,
-                                                                const uint32_t *res, uint8_t *adv_out, uint8_t *kind_out,
-                                                                uint8_t *exit_out, uint16_t *bits_out) {
-    static_assert(DECIDE_THREADS == TILE, "one thread per position of a tile");
-    __shared__ uint32_t s_pb[2][TILE];
-    const Seg sg = segs[blockIdx.y];
-    const int n = (int)sg.n;
-    const int tbase = (int)(blockIdx.x * TILE), tend = tbase + TILE;
-    if (tbase >= n || tend <= (int)sg.start) return;
-    const int x = (int)threadIdx.x;
-    const int i = tbase + x;
-    const bool valid = i < n && i >= (int)sg.start;
-    const uint8_t *T = text + sg.off;
-    const uint32_t *R = res + sg.off;
+// One WAVE per 256-position tile, four positions per lane (four tiles per workgroup; the waves never meet, so there
+// is no workgroup barrier).  The tile's rows come in and leave as whole words - text, run lengths and the four output
+// rows one instruction each, the results as one 16-byte load per lane - and the neighbours a position looks at
+// (i - 1, i + 1, i + 2) are the next bytes / words of the same lane or of the lane beside it.  After the phrase at every
+// position is known, the tile also resolves, for every position x, where the chain x -> x + advance(x) first lands
+// past the tile and how many phrase bits it writes on the way (pointer doubling in LDS: <= 8 rounds, fewer when every
+// chain has left the tile) - what walk_kernel needs to hop from tile to tile without ever walking inside one.
+__device__ inline void decide_one(int i, int n, int tbase, int tend, bool valid, uint32_t c, uint32_t prev, uint32_t next, int count,
+                                  uint32_t r0, uint32_t r1, uint32_t r2, const uint8_t *T, uint32_t &adv, uint32_t &kind_o, uint32_t &p,
+                                  uint32_t &bits) {
     int advance = 1;
     uint8_t kind = K_LIT;
     if (valid) {
-        const uint8_t c = T[i];
         const bool reserved = c >= LZSS_SYMBOL_SHORT;
         // run of equal bytes starting at i, capped at 256 and at the end of the buffer (compress.go:180-183)
         const int lim = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
-        int count = rlen[sg.off + i];  // the suffix sort's run lengths, capped at 255
-        if (count == 255 && lim > 255 && T[i + 255] == c) count = 256;
+        if (count == 255 && lim > 255 && T[i + 255] == c) count = 256;  // (the suffix sort's run lengths are capped at 255)
         if (count > lim) count = lim;
         if (count >= LZSS_MIN_REPEAT) {  // compress.go:184-218
             advance = count;
-            if (i > 0 && T[i - 1] == c) kind = K_RLE_CONT;
+            if (i > 0 && prev == c) kind = K_RLE_CONT;
             else kind = reserved ? K_RLE_RES : K_RLE_LIT;
         } else {
-            const uint32_t r0 = R[i];
             const int s0 = savings_of(r0);
             const uint8_t refkind = res_type(r0) == RES_SHORT ? K_SHORT : K_DYN;
             if (reserved) {  // compress.go:221-226 (a dictionary reference of length 1 always exists)
@@ -74,10 +63,10 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs,
             } else if (s0 < 0) {  // compress.go:227-232
                 kind = K_LIT;
                 advance = 1;
-            } else if (i + 1 < n && savings_of(R[i + 1]) > s0 + 1) {  // compress.go:235-242
+            } else if (i + 1 < n && savings_of(r1) > s0 + 1) {  // compress.go:235-242
                 kind = K_LIT;
                 advance = 1;
-            } else if (i + 2 < n && T[i + 1] < LZSS_SYMBOL_SHORT && savings_of(R[i + 2]) > s0 + 2) {  // :243-253
+            } else if (i + 2 < n && next < LZSS_SYMBOL_SHORT && savings_of(r2) > s0 + 2) {  // :243-253
                 kind = K_LIT2;
                 advance = 2;
             } else {  // compress.go:255-256
@@ -85,41 +74,98 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs,
                 advance = (int)res_len(r0);
             }
         }
-        adv_out[sg.off + i] = (uint8_t)(advance - 1);
-        kind_out[sg.off + i] = kind;
     }
     // chain state: < TILE = position inside the tile; TILE + e = left the tile, landing e positions into the next one
     // (e = 0 also stands for "past the end of the text": the hop loop of walk_kernel stops there on its own)
-    uint32_t p = TILE, bits = 0;
+    p = TILE;
+    bits = 0;
     if (valid) {
         const int nx = i + advance;
         p = nx >= tend ? (uint32_t)(TILE + nx - tend) : (nx >= n ? (uint32_t)TILE : (uint32_t)(nx - tbase));
         bits = kind_bits(kind);
     }
+    adv = (uint32_t)(advance - 1);
+    kind_o = kind;
+}
+
+__global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs, const uint8_t *text, const uint8_t *rlen,
+                                                                const uint32_t *res, uint8_t *adv_out, uint8_t *kind_out,
+                                                                uint8_t *exit_out, uint16_t *bits_out) {
+    __shared__ uint32_t s_pb_all[DECIDE_THREADS / 64][2][TILE];
+    const Seg sg = segs[blockIdx.y];
+    const int n = (int)sg.n;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tbase = (int)((blockIdx.x * (DECIDE_THREADS / 64) + w) * TILE), tend = tbase + TILE;
+    if (tbase >= n || tend <= (int)sg.start) return;
+    uint32_t (*s_pb)[TILE] = s_pb_all[w];
+    const uint8_t *T = text + sg.off;
+    const uint32_t *R = res + sg.off;
+    const size_t gbase = (size_t)sg.off + (size_t)tbase;  // a multiple of 256: the rows are word aligned, and the arrays
+                                                          // are padded to whole tiles, so the whole rows are readable
+    const uint32_t tw = reinterpret_cast<const uint32_t *>(text + gbase)[lane];
+    const uint32_t rw = reinterpret_cast<const uint32_t *>(rlen + gbase)[lane];
+    const uint4 rr = reinterpret_cast<const uint4 *>(res + gbase)[lane];
+    // what the lane's last positions see in the next lane / the next tile, and its first one in the previous
+    uint32_t tn = (uint32_t)__shfl_down((int)tw, 1), tp = (uint32_t)__shfl_up((int)tw, 1) >> 24;
+    uint32_t rn0 = (uint32_t)__shfl_down((int)rr.x, 1), rn1 = (uint32_t)__shfl_down((int)rr.y, 1);
+    if (lane == 63) {
+        tn = tend < n ? (uint32_t)T[tend] : 0u;
+        rn0 = tend < n ? R[tend] : 0u;
+        rn1 = tend + 1 < n ? R[tend + 1] : 0u;
+    }
+    if (lane == 0) tp = tbase > 0 ? (uint32_t)T[tbase - 1] : 0u;
+    const uint32_t r[6] = {rr.x, rr.y, rr.z, rr.w, rn0, rn1};
+    const uint32_t tb[6] = {tp, tw & 0xFFu, (tw >> 8) & 0xFFu, (tw >> 16) & 0xFFu, tw >> 24, tn & 0xFFu};
+    uint32_t adv[4], kind[4], p[4], bits[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = 4 * lane + j, i = tbase + x;
+        const bool valid = i < n && i >= (int)sg.start;
+        decide_one(i, n, tbase, tend, valid, tb[j + 1], tb[j], tb[j + 2], (int)((rw >> (8 * j)) & 0xFFu), r[j], r[j + 1], r[j + 2], T,
+                   adv[j], kind[j], p[j], bits[j]);
+    }
     // one word per position: chain state in the low half, bits so far in the high half (<= 9539 bits per tile)
     int cur = 0;
-    s_pb[0][x] = p | (bits << 16);
-    __syncthreads();
+    {
+        uint4 v;
+        v.x = p[0] | (bits[0] << 16); v.y = p[1] | (bits[1] << 16); v.z = p[2] | (bits[2] << 16); v.w = p[3] | (bits[3] << 16);
+        reinterpret_cast<uint4 *>(s_pb[0])[lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
     for (int k = 0; k < 8; ++k) {
-        if (p < (uint32_t)TILE) {
-            const uint32_t v = s_pb[cur][p];
-            bits += v >> 16;
-            p = v & 0xFFFFu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (p[j] < (uint32_t)TILE) {
+                const uint32_t v = s_pb[cur][p[j]];
+                bits[j] += v >> 16;
+                p[j] = v & 0xFFFFu;
+            }
         }
-        s_pb[cur ^ 1][x] = p | (bits << 16);
+        uint4 v;
+        v.x = p[0] | (bits[0] << 16); v.y = p[1] | (bits[1] << 16); v.z = p[2] | (bits[2] << 16); v.w = p[3] | (bits[3] << 16);
+        reinterpret_cast<uint4 *>(s_pb[cur ^ 1])[lane] = v;
         cur ^= 1;
-        if (__syncthreads_count(p < (uint32_t)TILE) == 0) break;
+        __builtin_amdgcn_wave_barrier();
+        const bool more = p[0] < (uint32_t)TILE || p[1] < (uint32_t)TILE || p[2] < (uint32_t)TILE || p[3] < (uint32_t)TILE;
+        if (__ballot(more) == 0) break;
     }
-    if (valid) {
-        exit_out[sg.off + i] = (uint8_t)(p - TILE);
-        bits_out[sg.off + i] = (uint16_t)bits;
-    }
+    // rows out (positions outside [start, n) of a tile that meets it get the values of an unvisited position; nobody
+    // reads them: chains only move forward from `start`, and the emitter stops at n)
+    reinterpret_cast<uint32_t *>(adv_out + gbase)[lane] = adv[0] | (adv[1] << 8) | (adv[2] << 16) | (adv[3] << 24);
+    reinterpret_cast<uint32_t *>(kind_out + gbase)[lane] = kind[0] | (kind[1] << 8) | (kind[2] << 16) | (kind[3] << 24);
+    reinterpret_cast<uint32_t *>(exit_out + gbase)[lane] =
+        ((p[0] - TILE) & 0xFFu) | (((p[1] - TILE) & 0xFFu) << 8) | (((p[2] - TILE) & 0xFFu) << 16) | (((p[3] - TILE) & 0xFFu) << 24);
+    uint2 bo;
+    bo.x = (bits[0] & 0xFFFFu) | (bits[1] << 16);
+    bo.y = (bits[2] & 0xFFFFu) | (bits[3] << 16);
+    reinterpret_cast<uint2 *>(bits_out + gbase)[lane] = bo;
 }
 
 void launch_decide(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint8_t *d_rlen,
                    const uint32_t *d_res, const WalkWork &ww, hipStream_t stream) {
     if (n_segs == 0 || max_n == 0) return;
-    dim3 g((max_n + DECIDE_THREADS - 1) / DECIDE_THREADS, n_segs);
+    const uint32_t tiles = (max_n + TILE - 1) / TILE, per_wg = DECIDE_THREADS / 64;
+    dim3 g((tiles + per_wg - 1) / per_wg, n_segs);
     hipLaunchKernelGGL(decide_kernel, g, dim3(DECIDE_THREADS), 0, stream, d_segs, d_text, d_rlen, d_res, ww.adv, ww.kind,
                        ww.exitoff, ww.tbits);
 }
