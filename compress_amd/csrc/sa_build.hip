@@ -344,7 +344,17 @@ __global__ __launch_bounds__(SA_THREADS) void sa_build_full_kernel(const Seg *se
 //   late rounds:   when few suffixes are left, the records (RK[p], RK[p + h], p) come straight from the `act`
 //                  bitmap and are sorted by both keys (four passes over m records, no sweep over N slots)
 // Suffixes alone in their group never move again, so SA and the ranks are updated in place.
-constexpr int SA_INIT_DIGITS = 4;  // 9-bit digits of the initial keys
+#ifndef SA_KEY_Z
+#define SA_KEY_Z 1
+#endif
+// 9-bit digits of the initial keys: (c, run code, x, y) and, for texts of up to 2^18 suffixes - whose index leaves room for
+// a fifth digit in the 8-byte record - also z, the third symbol after the run
+template <int DB> struct SaInit {
+    static constexpr bool Z = SA_KEY_Z && DB <= 9;
+    static constexpr int DIGITS = Z ? 5 : 4;
+    static constexpr int SHIFT = Z ? 19 : 20;          // record = key << SHIFT | suffix
+    static constexpr uint32_t H0 = Z ? 4 : 3;          // symbols every key group shares at least
+};
 #ifndef SA_MAIN_THREADS
 #define SA_MAIN_THREADS 512
 #endif
@@ -645,6 +655,7 @@ template <bool INITIAL, int DB>
 __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uint64_t *rec, uint32_t m, int32_t *sa,
                                       int32_t *rk, int tid) {
     constexpr int NB = 1 << DB;
+    constexpr int RS = INITIAL ? SaInit<DB>::SHIFT : 20;  // bits of the suffix index below the key(s)
     const int lane = tid & 63, w = tid >> 6;
     int tileK = -1, tileS = -1;
     uint32_t rem = 0;
@@ -660,15 +671,15 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             p[s] = 0;
             if (u < m) {
                 const uint64_t r = rec[u];
-                p[s] = (int)(r & 0xFFFFFu);
-                key[s] = r >> 20;
+                p[s] = (int)(r & ((1u << RS) - 1u));
+                key[s] = r >> RS;
             }
         }
         // neighbours across the wave's span (uniform loads)
         uint64_t pkey = 0, nkey = 0;
         const uint32_t un = wb + SA_WSPAN;
-        if (wb > 0 && wb < m) pkey = rec[wb - 1] >> 20;
-        if (un < m) nkey = rec[un] >> 20;
+        if (wb > 0 && wb < m) pkey = rec[wb - 1] >> RS;
+        if (un < m) nkey = rec[un] >> RS;
 
         // per entry: bit 0 = first of its group, bit 1 = first of its (group, second key) run, bit 2 = alone
         int fl[SA_K];
@@ -806,6 +817,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     //      blobs: the doubling rounds move 0.98 N suffixes in total instead of 2.44 N after a plain 4-symbol key).
     //      One sweep builds the records (key << 20 | suffix) in text order and counts the four digits.
     int32_t *hY = (int32_t *)L.act, *hX = hY + NB, *hC = L.hl, *hS = L.hh;  // act is free until the first regroup
+    int32_t *hZ = L.hy;                                                       // (a late round's array)
     {
         // Every wave sweeps a contiguous range of 64-position blocks, so the "byte == next byte" ballots that give the
         // run lengths slide: a block's run lengths read the flags of itself and the next four blocks (exact up to 257),
@@ -850,22 +862,26 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             const bool valid = e < N;
             if (valid) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
             uint64_t rec = 0;
-            int dY = 0, dX = 0, dC = 0, dS = 0;
+            int dZ = 0, dY = 0, dX = 0, dC = 0, dS = 0;
             if (valid) {
                 dS = e < n ? (int)T[e] + 1 : 0;
                 if (rl >= SA_RUN_CAP) {
                     dC = 255;
                 } else {
-                    const uint32_t q = e + (uint32_t)rl;  // the two symbols after the run, one load (the text is zero padded)
-                    uint16_t v;
-                    __builtin_memcpy(&v, T + q, 2);
+                    const uint32_t q = e + (uint32_t)rl;  // the symbols after the run, one load (the text is zero padded)
+                    uint32_t v;
+                    __builtin_memcpy(&v, T + q, 4);
                     dX = q < n ? (int)(v & 0xFFu) + 1 : 0;
-                    dY = q + 1 < n ? (int)(v >> 8) + 1 : 0;
+                    dY = q + 1 < n ? (int)((v >> 8) & 0xFFu) + 1 : 0;
+                    dZ = q + 2 < n ? (int)((v >> 16) & 0xFFu) + 1 : 0;
                     dC = dX < dS ? rl : 511 - rl;
                 }
-                rec = ((((((uint64_t)dS << 9) | (uint64_t)dC) << 9 | (uint64_t)dX) << 9 | (uint64_t)dY) << 20) | (uint64_t)e;
+                rec = ((((((uint64_t)dS << 9) | (uint64_t)dC) << 9) | (uint64_t)dX) << 9) | (uint64_t)dY;
+                if (SaInit<DB>::Z) rec = (rec << 9) | (uint64_t)dZ;
+                rec = (rec << SaInit<DB>::SHIFT) | (uint64_t)e;
                 recB[e] = rec;
             }
+            if (SaInit<DB>::Z) digit_count(hZ, dZ, valid, lane);
             digit_count(hY, dY, valid, lane);
             digit_count(hX, dX, valid, lane);
             digit_count(hC, dC, valid, lane);
@@ -878,9 +894,10 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     {
         const uint64_t *rin = recB;
         uint64_t *rout = recA;
-        for (int pass = 0; pass < SA_INIT_DIGITS; ++pass) {
-            const int shift = 20 + 9 * pass;
-            bins_scan(pass == 0 ? hY : pass == 1 ? hX : pass == 2 ? hC : hS, L.base, NB, tid);
+        for (int pass = 0; pass < SaInit<DB>::DIGITS; ++pass) {
+            const int shift = SaInit<DB>::SHIFT + 9 * pass;
+            const int dg = pass + (SaInit<DB>::Z ? 0 : 1);  // 0: z, 1: y, 2: x, 3: run code, 4: first symbol
+            bins_scan(dg == 0 ? hZ : dg == 1 ? hY : dg == 2 ? hX : dg == 3 ? hC : hS, L.base, NB, tid);
             SA_PROF(15)
             // the records of the next tile are loaded while the current one is being placed
             auto load_rec = [&](uint32_t e) -> uint64_t {
@@ -921,7 +938,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             rout = (rout == recA) ? recB : recA;
         }
     }
-    const uint64_t *rcur = (SA_INIT_DIGITS & 1) ? recA : recB;
+    const uint64_t *rcur = (SaInit<DB>::DIGITS & 1) ? recA : recB;
     for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh
     for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;  // held two digit histograms so far
     __syncthreads();
@@ -929,7 +946,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     SA_PROF(15)
     uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid);
     SA_PROF(4)
-    uint32_t h = 3;  // every group of the initial keys shares at least 3 symbols
+    uint32_t h = SaInit<DB>::H0;  // every group of the initial keys shares at least that many symbols
     while (m != 0 && h < N && --max_rounds >= 0) {
         if ((uint64_t)m * SA_LATE_DIV <= N) {
             // ---- late round: few suffixes are left, so instead of sweeping the whole suffix array the records
