@@ -487,6 +487,7 @@ struct SaCarry {
     int32_t a[2][SAM_WAVES];
     int32_t b[2][SAM_WAVES];
     int32_t wcount[SAM_WAVES];
+    int32_t fin_cnt[4];   // small groups listed for sa_finish, by size (2, 3, 4); [3]: suffixes it has finished
 };
 
 // lanes of the wave (among `valid`) holding the same digit as this lane.  The most frequent digits are found
@@ -648,12 +649,67 @@ __device__ inline void scatter_pass(const SaLds<DB> &L, const uint64_t *in, uint
     __syncthreads();
 }
 
+// ---- small groups are finished by comparing their suffixes directly -------------------------------------------
+// Real repeats in the data this path sees are long (32-byte words): after the initial keys most shared groups hold 2-4
+// suffixes that stay together through the rounds with h = 4, 8, 16 and part at depth 32-64, and every such round costs
+// them a rank gather, two scatter passes and a regroup.  The regroup step therefore LISTS the groups of 2 .. SA_FIN_G
+// suffixes that lie inside one 64-entry step (one list per size, in the spare record buffer), and sa_finish then gives
+// every listed group to one lane: it compares the members' suffixes pairwise from the depth they are known to share,
+// up to SA_FIN_SPAN bytes further; if every pair is decided the members get their final slots and leave the active
+// set (the digit counts the regroup step made for them are taken back), otherwise the group goes on through the
+// rounds as before.  (Comparing inside the regroup sweep itself was 1.7x slower than no finishing at all: a step
+// waited for its slowest lane's chain of dependent loads while most lanes had no group.)
+#ifndef SA_FIN_G
+#define SA_FIN_G 4   // 1: no finishing; at most 4
+#endif
+static_assert(SA_FIN_G <= 4, "three lists");
+#ifndef SA_FIN_SPAN
+#define SA_FIN_SPAN 128
+#endif
+// order of the suffixes at pa and pb (pa != pb), which share their first d0 symbols: -1 (pa's is smaller), +1, or 0 when
+// they are still equal SA_FIN_SPAN bytes further.  The suffix that ends first is the smaller one (the sentinel).
+__device__ inline int suffix_cmp(const uint8_t *T, uint32_t n, uint32_t pa, uint32_t pb, int d0) {
+    const int lim = (int)(n - (pa > pb ? pa : pb));  // length of the shorter suffix
+    const int cap = d0 + SA_FIN_SPAN;
+    int o = d0;
+#ifndef SA_FIN_WIDE
+#define SA_FIN_WIDE 1
+#endif
+#if !SA_FIN_WIDE
+    while (o < cap && o < lim) {
+        const uint64_t x = ld8(T + pa + o) ^ ld8(T + pb + o);
+        if (x) {
+            o += (int)(__builtin_ctzll(x) >> 3);
+            break;
+        }
+        o += 8;
+    }
+#else
+    while (o < cap && o < lim) {  // 32 bytes per round trip (the text is readable 64 bytes past its end)
+        const uint64_t x0 = ld8(T + pa + o) ^ ld8(T + pb + o), x1 = ld8(T + pa + o + 8) ^ ld8(T + pb + o + 8);
+        const uint64_t x2 = ld8(T + pa + o + 16) ^ ld8(T + pb + o + 16), x3 = ld8(T + pa + o + 24) ^ ld8(T + pb + o + 24);
+        if (x0 | x1 | x2 | x3) {
+            if (x0) o += (int)(__builtin_ctzll(x0) >> 3);
+            else if (x1) o += 8 + (int)(__builtin_ctzll(x1) >> 3);
+            else if (x2) o += 16 + (int)(__builtin_ctzll(x2) >> 3);
+            else o += 24 + (int)(__builtin_ctzll(x3) >> 3);
+            break;
+        }
+        o += 32;
+    }
+#endif
+    if (o >= lim) return pa > pb ? -1 : 1;
+    const int ca = T[pa + o], cb = T[pb + o];  // (plain loads after the loop: see the note in match.hip, dict_search_in)
+    if (ca == cb) return 0;                    // the loop ran into the cap
+    return ca < cb ? -1 : 1;
+}
+
 // Regroup: `m` sorted records (INITIAL: (initial key, suffix) in key order, one group;
 // otherwise (k1, k2, suffix) sorted by (k1, sequence order)) -> slots, new group starts, bitmaps, next digit counts.
 // Returns the number of suffixes that still share their group.
 template <bool INITIAL, int DB>
 __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uint64_t *rec, uint32_t m, int32_t *sa,
-                                      int32_t *rk, int tid) {
+                                      int32_t *rk, int tid, uint32_t *fin_list, uint32_t fin_stride) {
     constexpr int NB = 1 << DB;
     constexpr int RS = INITIAL ? SaInit<DB>::SHIFT : 20;  // bits of the suffix index below the key(s)
     const int lane = tid & 63, w = tid >> 6;
@@ -698,6 +754,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
         int gKl[SA_K], gSl[SA_K];
         int runK = -1, runS = -1;
         uint64_t bS[SA_K];
+        bool nfend[SA_K];
 #pragma unroll
         for (int s = 0; s < SA_K; ++s) bS[s] = __ballot(fl[s] & 2);
         const uint64_t lem = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
@@ -710,6 +767,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             else if (s + 1 < SA_K) nf = bS[s + 1 < SA_K ? s + 1 : s] & 1;
             else nf = (un < m) ? (nkey != key[s]) : true;
             if (u + 1 >= m) nf = true;
+            nfend[s] = __shfl((int)nf, 63) != 0;  // the entry behind this step starts a run (or there is none)
             if ((fl[s] & 2) && nf) fl[s] |= 4;
             // index of the last marked entry at or before this one: from the ballots, no scans
             const int u0 = (int)(wb + s * 64);
@@ -735,6 +793,22 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             tileK = max(tileK, a);
             tileS = max(tileS, b);
         }
+        // small groups that lie inside a step: their first entry lists them for sa_finish (fsz = the group's size there)
+        int fsz[SA_K];
+#pragma unroll
+        for (int s = 0; s < SA_K; ++s) {
+            fsz[s] = 0;
+            if (SA_FIN_G < 2) continue;
+            const uint32_t u = wb + s * 64 + lane;
+            const bool valid = u < m;
+            const int nvalid = __popcll(__ballot(valid));
+            const uint64_t above = lane == 63 ? 0ull : (bS[s] >> (lane + 1));
+            int b = above ? lane + 1 + (int)__builtin_ctzll(above) : 64;     // lane behind the run's last entry
+            if (b > nvalid) b = nvalid;
+            const bool closed = b < nvalid || nvalid < 64 || nfend[s];
+            const int size = b - lane;
+            if (valid && (fl[s] & 2) && closed && size >= 2 && size <= SA_FIN_G) fsz[s] = size;
+        }
 #pragma unroll
         for (int s = 0; s < SA_K; ++s) {
             const uint32_t u = wb + s * 64 + lane;
@@ -744,6 +818,17 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             const int slot = k1 + ((int)u - gK);
             const int nr = k1 + (gS - gK);
             const bool fS = fl[s] & 2, sgl = fl[s] & 4;
+            if (SA_FIN_G >= 2) {
+#pragma unroll
+                for (int z = 2; z <= SA_FIN_G; ++z) {
+                    const uint64_t em = __ballot(fsz[s] == z);
+                    if (em == 0) continue;
+                    int base = 0;
+                    if (lane == (int)__builtin_ctzll(em)) base = atomicAdd(&cy.fin_cnt[z - 2], __popcll(em));
+                    base = __shfl(base, (int)__builtin_ctzll(em));
+                    if (fsz[s] == z) fin_list[(uint32_t)(z - 2) * fin_stride + (uint32_t)base + (uint32_t)__popcll(em & lanemask_lt(lane))] = (uint32_t)slot;
+                }
+            }
             if (valid) {
                 sa[slot] = p[s] | ((fS && !sgl) ? (int)0x80000000 : 0);  // top bit: first slot of a shared group
                 rk[p[s]] = nr;
@@ -775,6 +860,57 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
     return total;
 }
 
+// The listed groups (sa_regroup), one lane each: order the members by direct comparison; a group whose pairs are all
+// decided gets its final slots, leaves the active set and the next round's digit counts.  Returns the number of
+// suffixes finished.  d0: symbols the members of a group are known to share.
+template <int DB>
+__device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint32_t *fin_list, uint32_t fin_stride, int32_t *sa,
+                                     int32_t *rk, const uint8_t *T, uint32_t n, int d0, int tid) {
+    constexpr int NB = 1 << DB;
+    if (SA_FIN_G < 2) return 0;
+    __syncthreads();  // the lists, the slots and the counters are complete
+#pragma unroll
+    for (int z = 2; z <= SA_FIN_G; ++z) {
+        const uint32_t cnt = (uint32_t)cy.fin_cnt[z - 2];
+        for (uint32_t g = tid; g < cnt; g += SAM_THREADS) {
+            const uint32_t slot0 = fin_list[(uint32_t)(z - 2) * fin_stride + g];
+            uint32_t p[SA_FIN_G];
+#pragma unroll
+            for (int j = 0; j < z; ++j) p[j] = (uint32_t)sa[slot0 + j] & 0x7FFFFFFFu;
+            int place[SA_FIN_G];
+#pragma unroll
+            for (int j = 0; j < z; ++j) place[j] = 0;
+            bool und = false;
+#pragma unroll
+            for (int i = 0; i < z; ++i)
+#pragma unroll
+                for (int j = i + 1; j < z; ++j) {
+                    const int c = suffix_cmp(T, n, p[i], p[j], d0);
+                    und = und || c == 0;
+                    if (c > 0) ++place[i];
+                    else ++place[j];
+                }
+            if (und) continue;
+#pragma unroll
+            for (int j = 0; j < z; ++j) {
+                const uint32_t slot = slot0 + (uint32_t)place[j];
+                sa[slot] = (int)p[j];
+                rk[p[j]] = (int)slot;
+                atomicAnd(&L.act[p[j] >> 5], ~(1u << (p[j] & 31)));
+            }
+            atomicSub(&L.hl[slot0 & (NB - 1)], z);
+            atomicSub(&L.hh[slot0 >> DB], z);
+            atomicAdd(&cy.fin_cnt[3], z);
+        }
+    }
+    __syncthreads();
+    const uint32_t done = (uint32_t)cy.fin_cnt[3];
+    __syncthreads();
+    if (tid < 4) cy.fin_cnt[tid] = 0;
+    __syncthreads();
+    return done;
+}
+
 template <int DB>
 __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM_WAVES * SA_WGS_PER_CU / 4, SAM_WAVES * SA_WGS_PER_CU / 4))) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
     constexpr int NB = 1 << DB;
@@ -800,6 +936,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     uint64_t *recA = wk.recA + sg.off, *recB = wk.recB + sg.off;
 
     SA_PROF_DECL
+    if (tid < 4) cy.fin_cnt[tid] = 0;
     for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;
     for (int x = tid; x < 6 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh, hy
     for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
@@ -944,7 +1081,9 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     __syncthreads();
 
     SA_PROF(15)
-    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid);
+    const uint32_t fin_stride = N / 2 + 16;  // entries of a list: three lists fit a record buffer
+    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid, (uint32_t *)(rcur == recA ? recB : recA), fin_stride);
+    m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), fin_stride, sa, rk, T, n, (int)SaInit<DB>::H0, tid);
     SA_PROF(4)
     uint32_t h = SaInit<DB>::H0;  // every group of the initial keys shares at least that many symbols
     while (m != 0 && h < N && --max_rounds >= 0) {
@@ -1062,7 +1201,8 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh: refilled by the regroup below
         __syncthreads();
         // ---- D: new groups
-        m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid);
+        m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid, (uint32_t *)recA, fin_stride);
+        m -= sa_finish<DB>(L, cy, (const uint32_t *)recA, fin_stride, sa, rk, T, n, (int)(2 * h < (1u << 20) ? 2 * h : (1u << 20)), tid);
         SA_PROF(14)
         h *= 2;
     }
