@@ -1,5 +1,5 @@
 // sa_build.hip - suffix array + inverse of every segment of a batch, one workgroup per segment (gfx950):
-// 512 threads in the main kernel (three workgroups per CU: 52 KiB of LDS and 80 VGPRs each), 1024 in the fallback for texts of 512 KiB and more.  Replaces suffixarray.New (lzss/internal/suffixarray/suffixarray.go:32-45, which
+// 512 threads in the main kernel (two workgroups per CU), 1024 in the fallback for texts of 512 KiB and more.  Replaces suffixarray.New (lzss/internal/suffixarray/suffixarray.go:32-45, which
 // runs SA-IS, sais.go:128-203) for both the input index (lzss/compress.go:116) and the dictionary
 // index (compress.go:64).  The suffix array of a text is a unique object, so the construction is
 // free to be GPU-shaped: prefix doubling (Manber-Myers bucket induction), every round one stable
@@ -360,7 +360,7 @@ template <int DB> struct SaInit {
 #define SA_MAIN_THREADS 512
 #endif
 #ifndef SA_MAIN_K
-#define SA_MAIN_K 4
+#define SA_MAIN_K 8
 #endif
 #ifndef SA_USE_MTAB
 #define SA_USE_MTAB 1
@@ -375,12 +375,12 @@ template <int DB> struct SaInit {
 #define SA_PROF_PRINT
 #endif
 #ifndef SA_MTAB_BITS
-#define SA_MTAB_BITS 7
+#define SA_MTAB_BITS 10
 #endif
 constexpr int SA_MTB = SA_MTAB_BITS;     // digit bits resolved by the table (the rest by ballots)
 constexpr int SA_MTB_WIDE = 8;           // the same for the 10-bit-digit instantiation
 #ifndef SA_WGS_PER_CU
-#define SA_WGS_PER_CU 3
+#define SA_WGS_PER_CU 2   // (3 with SA_MAIN_K 4 and SA_MTAB_BITS 7: 80 VGPRs; slower once the finisher was in: 85.9 vs 81.9 ms)
 #endif
 constexpr bool SA_MTAB = SA_USE_MTAB;    // lanes with equal digits find each other through a bit table in LDS
 constexpr int SAM_THREADS = SA_MAIN_THREADS;
