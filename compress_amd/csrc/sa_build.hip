@@ -488,7 +488,7 @@ struct SaCarry {
     int32_t a[2][SAM_WAVES];
     int32_t b[2][SAM_WAVES];
     int32_t wcount[SAM_WAVES];
-    int32_t fin_cnt[4];   // small groups listed for sa_finish, by size (2, 3, 4); [3]: suffixes it has finished
+    int32_t fin_cnt[8];   // small groups listed for sa_finish, by size (2 .. 8 at [0 .. 6]); [7]: suffixes it has finished
 };
 
 // lanes of the wave (among `valid`) holding the same digit as this lane.  The most frequent digits are found
@@ -661,9 +661,16 @@ __device__ inline void scatter_pass(const SaLds<DB> &L, const uint64_t *in, uint
 // rounds as before.  (Comparing inside the regroup sweep itself was 1.7x slower than no finishing at all: a step
 // waited for its slowest lane's chain of dependent loads while most lanes had no group.)
 #ifndef SA_FIN_G
-#define SA_FIN_G 4   // 1: no finishing; at most 4
+#define SA_FIN_G 5   // 1: no finishing; at most 8 (measured: 4 82.0, 5 81.0, 6 81.0, 8 92.3 ms per 10 000 blobs)
 #endif
-static_assert(SA_FIN_G <= 4, "three lists");
+static_assert(SA_FIN_G <= 8, "seven lists");
+// first entry of the list of the groups of z suffixes: a text of N suffixes has at most N / z of them (all lists
+// together, sizes 2 .. 8: 1.72 N four-byte entries - they fit the spare 8-byte-per-suffix record buffer)
+__device__ inline uint32_t fin_list_base(int z, uint32_t N) {
+    uint32_t b = 0;
+    for (int y = 2; y < z; ++y) b += N / (uint32_t)y + 1;
+    return b;
+}
 #ifndef SA_FIN_SPAN
 #define SA_FIN_SPAN 128
 #endif
@@ -710,7 +717,7 @@ __device__ inline int suffix_cmp(const uint8_t *T, uint32_t n, uint32_t pa, uint
 // Returns the number of suffixes that still share their group.
 template <bool INITIAL, int DB>
 __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uint64_t *rec, uint32_t m, int32_t *sa,
-                                      int32_t *rk, int tid, uint32_t *fin_list, uint32_t fin_stride) {
+                                      int32_t *rk, int tid, uint32_t *fin_list, uint32_t fin_N) {
     constexpr int NB = 1 << DB;
     constexpr int RS = INITIAL ? SaInit<DB>::SHIFT : 20;  // bits of the suffix index below the key(s)
     const int lane = tid & 63, w = tid >> 6;
@@ -827,7 +834,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
                     int base = 0;
                     if (lane == (int)__builtin_ctzll(em)) base = atomicAdd(&cy.fin_cnt[z - 2], __popcll(em));
                     base = __shfl(base, (int)__builtin_ctzll(em));
-                    if (fsz[s] == z) fin_list[(uint32_t)(z - 2) * fin_stride + (uint32_t)base + (uint32_t)__popcll(em & lanemask_lt(lane))] = (uint32_t)slot;
+                    if (fsz[s] == z) fin_list[fin_list_base(z, fin_N) + (uint32_t)base + (uint32_t)__popcll(em & lanemask_lt(lane))] = (uint32_t)slot;
                 }
             }
             if (valid) {
@@ -865,7 +872,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
 // decided gets its final slots, leaves the active set and the next round's digit counts.  Returns the number of
 // suffixes finished.  d0: symbols the members of a group are known to share.
 template <int DB>
-__device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint32_t *fin_list, uint32_t fin_stride, int32_t *sa,
+__device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint32_t *fin_list, uint32_t fin_N, int32_t *sa,
                                      int32_t *rk, const uint8_t *T, uint32_t n, int d0, int tid) {
     constexpr int NB = 1 << DB;
     if (SA_FIN_G < 2) return 0;
@@ -874,7 +881,7 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
     for (int z = 2; z <= SA_FIN_G; ++z) {
         const uint32_t cnt = (uint32_t)cy.fin_cnt[z - 2];
         for (uint32_t g = tid; g < cnt; g += SAM_THREADS) {
-            const uint32_t slot0 = fin_list[(uint32_t)(z - 2) * fin_stride + g];
+            const uint32_t slot0 = fin_list[fin_list_base(z, fin_N) + g];
             uint32_t p[SA_FIN_G];
 #pragma unroll
             for (int j = 0; j < z; ++j) p[j] = (uint32_t)sa[slot0 + j] & 0x7FFFFFFFu;
@@ -901,13 +908,13 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
             }
             atomicSub(&L.hl[slot0 & (NB - 1)], z);
             atomicSub(&L.hh[slot0 >> DB], z);
-            atomicAdd(&cy.fin_cnt[3], z);
+            atomicAdd(&cy.fin_cnt[7], z);
         }
     }
     __syncthreads();
-    const uint32_t done = (uint32_t)cy.fin_cnt[3];
+    const uint32_t done = (uint32_t)cy.fin_cnt[7];
     __syncthreads();
-    if (tid < 4) cy.fin_cnt[tid] = 0;
+    if (tid < 8) cy.fin_cnt[tid] = 0;
     __syncthreads();
     return done;
 }
@@ -937,7 +944,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     uint64_t *recA = wk.recA + sg.off, *recB = wk.recB + sg.off;
 
     SA_PROF_DECL
-    if (tid < 4) cy.fin_cnt[tid] = 0;
+    if (tid < 8) cy.fin_cnt[tid] = 0;
     for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;
     for (int x = tid; x < 6 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh, hy
     for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
@@ -1083,9 +1090,8 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     __syncthreads();
 
     SA_PROF(15)
-    const uint32_t fin_stride = N / 2 + 16;  // entries of a list: three lists fit a record buffer
-    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid, (uint32_t *)(rcur == recA ? recB : recA), fin_stride);
-    m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), fin_stride, sa, rk, T, n, (int)SaInit<DB>::H0, tid);
+    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid, (uint32_t *)(rcur == recA ? recB : recA), N);
+    m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), N, sa, rk, T, n, (int)SaInit<DB>::H0, tid);
     SA_PROF(4)
     uint32_t h = SaInit<DB>::H0;  // every group of the initial keys shares at least that many symbols
 #ifdef SA_PROFILE
@@ -1209,8 +1215,8 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh: refilled by the regroup below
         __syncthreads();
         // ---- D: new groups
-        m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid, (uint32_t *)recA, fin_stride);
-        m -= sa_finish<DB>(L, cy, (const uint32_t *)recA, fin_stride, sa, rk, T, n, (int)(2 * h < (1u << 20) ? 2 * h : (1u << 20)), tid);
+        m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid, (uint32_t *)recA, N);
+        m -= sa_finish<DB>(L, cy, (const uint32_t *)recA, N, sa, rk, T, n, (int)(2 * h < (1u << 20) ? 2 * h : (1u << 20)), tid);
         SA_PROF(14)
         h *= 2;
     }
