@@ -144,6 +144,29 @@ __device__ inline int lcp_bytes16(const uint8_t *a, const uint8_t *b, int from, 
     return o < lim ? o : lim;
 }
 
+// the same with ONE 16-byte load per side and step (one pass through the texture addresser instead of two)
+typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
+__device__ inline u64x2_t ld16(const uint8_t *p) {
+    typedef u64x2_t unaligned_t __attribute__((aligned(1)));
+    return *reinterpret_cast<const unaligned_t *>(p);
+}
+__device__ inline int lcp_bytes_x16(const uint8_t *a, const uint8_t *b, int from, int lim) {
+    int o = from;
+    while (o < lim) {
+        const u64x2_t x = ld16(a + o) ^ ld16(b + o);
+        if (x[0]) {
+            o += (int)(__builtin_ctzll(x[0]) >> 3);
+            break;
+        }
+        if (x[1]) {
+            o += 8 + (int)(__builtin_ctzll(x[1]) >> 3);
+            break;
+        }
+        o += 16;
+    }
+    return o < lim ? o : lim;
+}
+
 // common prefix length of the suffixes at a and b (a != b), at most lim, with the run lengths RL of the text (length
 // of the run of equal bytes starting at every position, capped at 255): different run lengths settle the answer
 // without a text compare, equal ones let it start behind the run (long runs are what makes prefixes long here)
@@ -173,7 +196,11 @@ __device__ inline int lcp_run_rank(const uint8_t *T, uint32_t a, uint32_t b, uin
         return l < lim ? l : lim;
     }
     const int from = r > 8 ? r : 8;
+#ifndef LCP_NARROW
+    return lcp_bytes_x16(T + a, T + b, from < lim ? from : lim, lim);
+#else
     return lcp_bytes(T + a, T + b, from < lim ? from : lim, lim);
+#endif
 }
 
 typedef uint16_t u16x8_t __attribute__((ext_vector_type(8)));

@@ -123,6 +123,105 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint3
     }
 }
 
+// The same for texts that fit LDS (up to LCP_LDS_MAX_N bytes): one 1024-thread workgroup per segment stages the whole
+// text in LDS once (coalesced), and every scattered text read of the kernel - a suffix's first 8 bytes, the compare
+// loop behind them - becomes an LDS read.  The global version is bound by the texture addresser (TA_BUSY 85 %: a
+// wave-wide load whose lanes hit 64 different lines costs ~250 cycles of it); here the only global traffic left is the
+// suffix array in (prefetched one step ahead) and the LCP array out, both streams.
+constexpr int LCPL_THREADS = 1024;
+constexpr uint32_t LCP_LDS_MAX_N = 150000;
+__global__ __launch_bounds__(LCPL_THREADS) void lcp_lds_kernel(const Seg *segs, BatchIndex ix) {
+    extern __shared__ uint32_t s_t32[];  // the text as words, zero padded (the 64 zero bytes behind it come along)
+    const Seg sg = segs[blockIdx.x];
+    const uint32_t n = sg.n, N = n + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint8_t *T = ix.text + sg.off;
+    const uint8_t *RL = ix.rlen + sg.off;
+    const int32_t *SA = ix.sa + sg.off;
+    const uint32_t words = (n + 32) / 4 + 1;  // every 8-byte read below starts at or before n + 8 (compares stop at lim)
+    for (uint32_t x = tid; x < words; x += LCPL_THREADS) s_t32[x] = reinterpret_cast<const uint32_t *>(T)[x];
+    __syncthreads();
+    auto ld8s = [&](uint32_t p) -> uint64_t {  // 8 bytes at any byte offset of the staged text
+        const uint32_t i0 = p >> 2, sh = p & 3u;
+        const uint32_t a0 = s_t32[i0], a1 = s_t32[i0 + 1], a2 = s_t32[i0 + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, sh), hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+    };
+    auto run_at = [&](int pos, uint64_t wd) -> int {
+        const uint64_t x = wd ^ ((wd & 0xFFull) * 0x0101010101010101ull);
+        if (x == 0) return (int)RL[pos];
+        const int r8 = (int)(__builtin_ctzll(x) >> 3), rest = (int)n - pos;
+        return r8 < rest ? r8 : rest;
+    };
+    int sak_next = (uint32_t)tid < N ? SA[tid] : INT_MAX;
+    for (uint32_t base = 0; base < N; base += LCPL_THREADS) {
+        const uint32_t k = base + (uint32_t)tid;
+        const int sak = sak_next;
+        sak_next = k + LCPL_THREADS < N ? SA[k + LCPL_THREADS] : INT_MAX;  // in flight while this step computes
+        uint32_t l = 0xFFFFu;
+        uint64_t wb = 0;
+        int rb = 0;
+        if (k < N) {
+            wb = ld8s((uint32_t)sak);
+            rb = run_at(sak, wb);
+        }
+        int a = __shfl_up(sak, 1);
+        uint64_t wa = __shfl_up(wb, 1);
+        int ra = __shfl_up(rb, 1);
+        if (lane == 0 && k > 0 && k < N) {
+            a = SA[k - 1];
+            wa = ld8s((uint32_t)a);
+            ra = run_at(a, wa);
+        }
+        if (k < N) {
+            l = 0;
+            if (k > 0) {
+                const uint32_t hi = (uint32_t)(a > sak ? a : sak);
+                int lim = (int)(n - hi);
+                if (lim > LZSS_MAX_LEN) lim = LZSS_MAX_LEN;
+                // lcp_run_rank with the compare loop on the staged text
+                const uint64_t x = wa ^ wb;
+                if (lim <= 0 || (x & 0xFFull)) l = 0;
+                else {
+                    const int r = ra < rb ? ra : rb;
+                    if (ra != rb) l = (uint32_t)(r < lim ? r : lim);
+                    else if (x) {
+                        const int q = (int)(__builtin_ctzll(x) >> 3);
+                        l = (uint32_t)(q < lim ? q : lim);
+                    } else {
+                        int o = r > 8 ? r : 8;
+                        while (o < lim) {
+                            const uint64_t y = ld8s((uint32_t)a + (uint32_t)o) ^ ld8s((uint32_t)sak + (uint32_t)o);
+                            if (y) {
+                                o += (int)(__builtin_ctzll(y) >> 3);
+                                break;
+                            }
+                            o += 8;
+                        }
+                        l = (uint32_t)(o < lim ? o : lim);
+                    }
+                }
+            }
+            ix.lcp[sg.off + k] = (uint16_t)l;
+            if (k == N - 1)
+                for (uint32_t e = 0; e < 4; ++e) ix.lcp[sg.off + N + e] = 0;
+        }
+        uint32_t m = l;
+        int ms = sak;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+            const int u = __shfl_xor(ms, o);
+            m = t < m ? t : m;
+            ms = u < ms ? u : ms;
+        }
+        if (lane == 0 && k < N) {  // (a block past the last rank would land in the next segment's summaries)
+            ix.bmin1[sg.off / 64 + (k >> 6)] = (uint16_t)m;
+            ix.samin1[sg.off / 64 + (k >> 6)] = ms;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void bmin2_kernel(const Seg *segs, BatchIndex ix) {
     const Seg sg = segs[blockIdx.y];
     const uint32_t N = sg.n + 1;
@@ -143,7 +242,17 @@ void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchI
     if (n_segs == 0) return;
     const uint32_t N = max_n + 1;
     const uint32_t gx = (N + LCP_THREADS - 1) / LCP_THREADS;
-    hipLaunchKernelGGL(lcp_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(LCP_THREADS), 0, stream, d_segs, n_segs, gx, ix);
+    if (max_n <= LCP_LDS_MAX_N) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)lcp_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(((LCP_LDS_MAX_N + 32) / 4 + 1) * 4));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(lcp_lds_kernel, dim3(n_segs), dim3(LCPL_THREADS), ((max_n + 32) / 4 + 1) * 4, stream, d_segs, ix);
+    } else {
+        hipLaunchKernelGGL(lcp_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(LCP_THREADS), 0, stream, d_segs, n_segs, gx, ix);
+    }
     const uint32_t nb1 = (N + 63) / 64;
     dim3 g2((nb1 + 63) / 64, n_segs);
     hipLaunchKernelGGL(bmin2_kernel, g2, dim3(64), 0, stream, d_segs, ix);
