@@ -21,6 +21,7 @@
 //      first in-window entry from lo upward.
 // Positions below HEAD are done by brute force over their (tiny) window instead, because the expected
 // walk length from r to an in-window neighbour grows like n / i.
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -243,11 +244,14 @@ void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchI
     const uint32_t N = max_n + 1;
     const uint32_t gx = (N + LCP_THREADS - 1) / LCP_THREADS;
     if (max_n <= LCP_LDS_MAX_N) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<uint64_t> attr_devs{0};  // once per device (see launch_sa_build)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t dbit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_acquire) & dbit)) {
             (void)hipFuncSetAttribute((const void *)lcp_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(((LCP_LDS_MAX_N + 32) / 4 + 1) * 4));
-            attr_set = true;
+            attr_devs.fetch_or(dbit, std::memory_order_release);
         }
         hipLaunchKernelGGL(lcp_lds_kernel, dim3(n_segs), dim3(LCPL_THREADS), ((max_n + 32) / 4 + 1) * 4, stream, d_segs, ix);
     } else {

@@ -14,6 +14,7 @@
 // suffixes p >= N - h, whose first h symbols contain the sentinel and which are therefore already
 // alone in their group, so their place in the sequence does not matter: p = N - h + SA[j] keeps the
 // sequence a permutation of 0..N-1.
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -663,7 +664,8 @@ __device__ inline void scatter_pass(const SaLds<DB> &L, const uint64_t *in, uint
 #ifndef SA_FIN_G
 #define SA_FIN_G 5   // 1: no finishing; at most 8 (measured: 4 82.0, 5 81.0, 6 81.0, 8 92.3 ms per 10 000 blobs)
 #endif
-static_assert(SA_FIN_G <= 8, "seven lists");
+static_assert(SA_FIN_G <= 8, "seven lists");  // (entries that also carry the members' positions, so that sa_finish
+// need not read them back from the suffix array, cost more in the regroup sweep than they saved: 83.3 vs 80.9 ms)
 // first entry of the list of the groups of z suffixes: a text of N suffixes has at most N / z of them (all lists
 // together, sizes 2 .. 8: 1.72 N four-byte entries - they fit the spare 8-byte-per-suffix record buffer)
 __device__ inline uint32_t fin_list_base(int z, uint32_t N) {
@@ -1368,13 +1370,18 @@ void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const u
     constexpr int max_rounds = 1000;
 #endif
     const uint32_t N = max_n + 1;
-    static bool attr_set = false;  // both instantiations may use more than the default 64 KiB of dynamic LDS
-    if (!attr_set) {
+    // both instantiations may use more than the default 64 KiB of dynamic LDS; the attribute belongs to the function on
+    // ONE device, so it is set once per device (several contexts on several GPUs may live in one process)
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t dbit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & dbit)) {
         (void)hipFuncSetAttribute((const void *)sa_build_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)SaLds<9>::bytes(sa_bitmap_words<9>(1u << 18)));
         (void)hipFuncSetAttribute((const void *)sa_build_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)SaLds<10>::bytes(sa_bitmap_words<10>(SA_BITMAP_MAX_N)));
-        attr_set = true;
+        attr_devs.fetch_or(dbit, std::memory_order_release);
     }
     if (N <= (1u << 18)) {
         hipLaunchKernelGGL(sa_build_kernel<9>, dim3(n_segs), dim3(SAM_THREADS), SaLds<9>::bytes(sa_bitmap_words<9>(N)), stream,
