@@ -68,6 +68,8 @@ def pmc_traffic(stage, n_blobs):
     for line in lines[1:]:
         k, c, v, nd = line.rsplit(",", 3)
         k = k.replace("void ", "").split("<")[0]
+        if k == "lzss::lcp_lds_kernel":
+            k = "lzss::lcp_kernel"
         if k == kernel and c == "FETCH_SIZE":
             fetch += float(v) * 1024.0
         if k == kernel and c == "WRITE_SIZE":

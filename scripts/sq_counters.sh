@@ -12,14 +12,21 @@ groups=(
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"
  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"
  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
- "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE"
+ "TA_BUSY_avr GRBM_GUI_ACTIVE"
 )
-g=0
-for grp in "${groups[@]}"; do
+# a heartbeat on stdout while a counter run is silent (a run without output for 3 minutes is taken to be hung)
+( while sleep 30; do echo "[sq_counters] $(date +%T) still running"; done ) &
+hb=$!
+trap 'kill $hb 2>/dev/null' EXIT
+g=${SQ_FIRST_GROUP:-0}
+failed=0
+for grp in "${groups[@]:$g}"; do
+  echo "[sq_counters] group $g: $grp"
   rm -rf $out/${tag}_sq_$g
-  timeout -s KILL 150 rocprofv3 --pmc $grp -d $out/${tag}_sq_$g -o p --output-format csv -- python3 $root/bench.py --blobs $blobs --steps 1 --warmup 1 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-repeats 0 > $out/${tag}_sq_$g.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc $grp -d $out/${tag}_sq_$g -o p --output-format csv -- python3 $root/bench.py --blobs $blobs --steps 1 --warmup 1 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-repeats 0 > $out/${tag}_sq_$g.log 2>&1
   rc=$?
-  if [ $rc -ne 0 ]; then echo "group $g ($grp) failed rc=$rc"; tail -3 $out/${tag}_sq_$g.log; if [ $rc -ge 124 ]; then exit 1; fi; fi
+  # (after a kill nothing more is started on the GPU in this call; the summary below is host work)
+  if [ $rc -ne 0 ]; then echo "group $g ($grp) failed rc=$rc"; tail -3 $out/${tag}_sq_$g.log; if [ $rc -ge 124 ]; then failed=1; break; fi; fi
   g=$((g+1))
 done
 python3 - "$out" "$tag" "$blobs" <<'PY'
@@ -46,3 +53,4 @@ with open(f"{out}/{tag}_sq_counters.csv","w") as g:
         g.write(k+","+str(nl)+","+",".join(vals)+"\n")
 print(open(f"{out}/{tag}_sq_counters.csv").read())
 PY
+exit $failed
