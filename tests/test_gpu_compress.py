@@ -61,6 +61,56 @@ def test_index_matches_oracle(amd):
             assert lcp[r] == l
 
 
+def small_group_cases():
+    """inputs that stress the suffix sort's small-group finisher (sa_finish) and the LDS / global LCP kernels"""
+    rng = np.random.default_rng(11)
+    x = bytes(rng.integers(0, 256, 30000, dtype=np.uint8))
+    words = [bytes(rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(400)]
+    reps = b"".join(words[int(k)] for k in rng.integers(0, 400, 1500))          # 32-byte words, 2-6 copies each
+    near = b"".join(w[:31] + bytes([int(rng.integers(0, 256))]) for w in words[:300] for _ in range(3))
+    return [
+        x + x,                              # every suffix has one twin, prefixes far longer than the compare span
+        x[:5000] + x[:5000] + x[:5000],     # triples
+        reps,                               # groups of 2-6 that part at depth <= 32 .. 64
+        near,                               # groups that differ in the last byte of a word
+        reps[:4000] + reps[:4000][:-1],     # a suffix that is a prefix of another one (ends the text)
+        b"ab" * 3000 + b"a",                # one chain of nested suffixes
+        b"abcabd" * 700,                    # period 6 with two-way splits
+        bytes(200) + x[:300] + bytes(200) + x[:300] + bytes(150),  # runs of zeros around repeats
+        amd_blob_sized(149990), amd_blob_sized(150000), amd_blob_sized(150001),  # the LCP kernels' size threshold
+    ]
+
+
+def amd_blob_sized(n):
+    from compress_amd import synth
+    return (synth.blob(90) + synth.blob(91))[:n]
+
+
+def test_small_groups_and_lcp_variants_match_oracle(amd, dict_naive):
+    cases = small_group_cases()
+    oc = O.Compressor(dict_naive)
+    for group in (cases[:8], cases[8:9], cases[9:10], cases[10:]):  # the size threshold is per batch (largest text)
+        ctx = amd.batch.new_ctx(dict_naive)
+        b = amd.batch.Batch(ctx, len(group), sum(map(len, group)))
+        b.upload(group)
+        b.compress()
+        got = b.download()
+        for k, d in enumerate(group):
+            n = len(d)
+            sa, isa, lcp = b.index(k)
+            assert sa[0] == n
+            assert np.array_equal(sa[1:], O.suffix_array(d)), f"case {k} n={n}"
+            assert np.array_equal(isa[sa], np.arange(n + 1))
+            rng = np.random.default_rng(k)
+            for r in rng.integers(1, n + 1, 300):
+                a, c = int(sa[r - 1]), int(sa[r])
+                l = 0
+                while l < 256 and a + l < n and c + l < n and d[a + l] == d[c + l]:
+                    l += 1
+                assert lcp[r] == l, f"case {k} rank {r}"
+            assert got[k] == oc.compress(d), f"case {k} n={n}"
+
+
 def test_text_sizes_across_the_suffix_sort_variants(amd, dict_naive):
     """the suffix sort has three code paths by text size: 9-bit digits (N <= 2^18), 10-bit digits (N <= 2^19) and the
     every-round-sorts-everything fallback above; a batch picks one by its LARGEST text, so each is exercised with a
