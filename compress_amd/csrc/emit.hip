@@ -315,6 +315,17 @@ __device__ inline uint32_t resolve_field(const SegIndex &S, uint32_t r, int i, b
     return (uint32_t)(i - p - 1);
 }
 
+// address bits of a pending long reference: into the dictionary (backref.go:66 with the dictionary's smallest-rank
+// occurrence) or into the window
+__device__ inline uint32_t pending_dyn_field(const SegIndex &S, const DictView &D, uint32_t r, int i) {
+    if (res_type(r) == RES_DICT) {
+        const int kd = (int)res_field(r), Ld = (int)res_len(r);
+        const int pd = D.SA[prev_lower(D.LCP, D.bmin1, D.bmin2, kd, Ld)];
+        return (uint32_t)(i + (int)D.n - pd - 1) & 0x1FFFFFu;
+    }
+    return resolve_field(S, r, i, false) & 0x1FFFFFu;
+}
+
 // OR the nb (1..37) low bits of v into the MSB-first bit image w at bit offset o
 __device__ inline void image_put(uint32_t *w, uint32_t o, uint64_t v, int nb) {
     const uint64_t x = v << (64 - nb);
@@ -330,7 +341,7 @@ __device__ inline void image_put(uint32_t *w, uint32_t o, uint64_t v, int nb) {
 __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, const uint8_t *text,
                                                   const uint32_t *res, BatchIndex ix, DictView D, WalkWork ww, uint32_t header_bytes,
                                                   uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
-                                                  uint8_t *out_buf, uint64_t out_cap, int32_t *status) {
+                                                  uint8_t *out_buf, uint64_t out_cap, int32_t *status, int split) {
     __shared__ uint32_t s_kind32[64], s_adv32[64], s_text32[65], s_res[TILE], s_out[EMIT_WORDS];
     __shared__ uint16_t s_jump[7][TILE + 2];
     const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
     const size_t gbase = (size_t)sg.off + (size_t)tbase;
 
     // stage the tile (the arrays are padded to whole tiles; the byte after the tile belongs to the next tile, if any)
-    s_kind32[lane] = reinterpret_cast<const uint32_t *>(ww.kind + gbase)[lane];
+    s_kind32[lane] = reinterpret_cast<const uint32_t *>(ww.kind + gbase)[lane] & 0x7F7F7F7Fu;  // (bit 7: resolve_kernel's mark)
     s_adv32[lane] = reinterpret_cast<const uint32_t *>(ww.adv + gbase)[lane];
     s_text32[lane] = reinterpret_cast<const uint32_t *>(text + gbase)[lane];
     if (lane == 0) s_text32[64] = (t + 1 < ntiles) ? text[gbase + TILE] : 0u;
@@ -426,12 +437,17 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
         const uint32_t a = (uint32_t)s_adv[x] + 1u;
         uint64_t v1, v2 = 0;
         int n1, n2 = 0;
+        bool later = false;  // the address bits are left to resolve_kernel
         switch (k) {
             case K_LIT: v1 = s_text[x]; n1 = 8; break;
             case K_LIT2: v1 = ((uint64_t)s_text[x] << 8) | s_text[x + 1]; n1 = 16; break;
             case K_SHORT: {
                 const uint32_t r = s_res[x];
-                const uint32_t f = res_pending(r) ? resolve_field(S, r, i, true) : res_field(r);
+                uint32_t f = res_field(r);
+                if (res_pending(r)) {
+                    if (split) { f = 0; later = true; }
+                    else f = resolve_field(S, r, i, true);
+                }
                 v1 = ((uint64_t)LZSS_SYMBOL_SHORT << 22) | ((uint64_t)(res_len(r) - 1) << 14) | (f & 0x3FFFu);
                 n1 = LZSS_SHORT_BITS;
                 break;
@@ -439,12 +455,9 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
             case K_DYN: {
                 const uint32_t r = s_res[x];
                 uint32_t f = res_field(r);
-                if (res_type(r) == RES_DICT) {  // backref.go:66 with the dictionary's smallest-rank occurrence
-                    const int kd = (int)f, Ld = (int)res_len(r);
-                    const int pd = D.SA[prev_lower(D.LCP, D.bmin1, D.bmin2, kd, Ld)];
-                    f = (uint32_t)(i + (int)D.n - pd - 1) & 0x1FFFFFu;
-                } else if (res_pending(r)) {
-                    f = resolve_field(S, r, i, false);
+                if (res_type(r) == RES_DICT || res_pending(r)) {
+                    if (split) { f = 0; later = true; }
+                    else f = pending_dyn_field(S, D, r, i);
                 }
                 v1 = ((uint64_t)LZSS_SYMBOL_DYNAMIC << 29) | ((uint64_t)(res_len(r) - 1) << 21) | f;
                 n1 = LZSS_DYN_BITS;
@@ -468,6 +481,12 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
         }
         image_put(s_out, off[j], v1, n1);
         if (n2) image_put(s_out, off[j] + (uint32_t)n1, v2, n2);
+        if (later) {  // mark the position and leave the bit at which its address field ends (relative to the stream's first byte)
+            const uint32_t fe = (uint32_t)((b0 >> 3) << 3) + off[j] + (uint32_t)n1;
+            ww.kind[gbase + x] = (uint8_t)(k | 0x80u);
+            ww.tbits[gbase + x] = (uint16_t)fe;
+            ww.exitoff[gbase + x] = (uint8_t)(fe >> 16);
+        }
     }
     __syncthreads();
     const uint32_t nbytes = (lead + total + 7) >> 3, tailbits = (lead + total) & 7u;
@@ -485,14 +504,85 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
     }
 }
 
+// ---- the address bits emit_kernel left open ---------------------------------------------------------------------
+// In emit_kernel a wave owns one tile, and the handful of its phrases whose smallest-rank occurrence is still pending
+// (match_kernel's deferral) kept the whole wave waiting through their searches - chains of dependent loads with six
+// busy lanes in 64, half of that kernel's time.  In split mode emit_kernel writes those phrases with a zero address
+// field, marks their positions (bit 7 of `kind`) and leaves the bit at which the field ends (24 bits in `tbits` /
+// `exitoff`, which nobody reads after walk_kernel); this kernel then scans the marks of 8192 positions per workgroup into
+// an LDS queue and every lane takes one pending phrase: dense searches, and the field goes into the stream with byte-wide
+// atomic ORs (the emitter stored zeros there).
+constexpr int RESOLVE_THREADS = 256;
+constexpr int RESOLVE_CHUNK = 8192;
+constexpr uint32_t RESOLVE_MAX_N = 400000;  // 37 bits per input byte at worst: the field-end bit must fit 24 bits
+
+__global__ __launch_bounds__(RESOLVE_THREADS) void resolve_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, const uint32_t *res,
+                                                                  BatchIndex ix, DictView D, WalkWork ww, uint32_t header_bytes,
+                                                                  uint8_t *out_buf, uint64_t out_cap) {
+    __shared__ uint16_t s_q[RESOLVE_CHUNK];
+    __shared__ int s_cnt;
+    const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);
+    if (vb >= gx * n_segs) return;
+    const uint32_t si = vb / gx;
+    const Seg sg = segs[si];
+    const int n = (int)sg.n;
+    const int base = (int)(vb % gx) * RESOLVE_CHUNK;
+    if (base >= n) return;
+    const uint64_t ooff = ww.out_off[si];
+    if (ooff + ww.out_len[si] > out_cap) return;  // the emitter wrote nothing for this blob (MI355_LZSS_E_CAPACITY)
+    const int tid = threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const size_t gbase = (size_t)sg.off + (size_t)base;  // a multiple of 256; the rows are padded to whole tiles
+    const int words = ((n - base < RESOLVE_CHUNK ? n - base : RESOLVE_CHUNK) + 3) / 4;
+    for (int w = tid; w < words; w += RESOLVE_THREADS) {
+        uint32_t mk = reinterpret_cast<const uint32_t *>(ww.kind + gbase)[w] & 0x80808080u;
+        while (mk) {
+            const int b = (int)(__builtin_ctz(mk) >> 3);
+            mk &= mk - 1;
+            const int x = 4 * w + b;
+            if (base + x < n && base + x >= (int)sg.start) s_q[atomicAdd(&s_cnt, 1)] = (uint16_t)x;
+        }
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    const SegIndex S = seg_index(ix, sg);
+    uint8_t *outp = out_buf + ooff + header_bytes;
+    for (int q = tid; q < cnt; q += RESOLVE_THREADS) {
+        const int x = (int)s_q[q], i = base + x;
+        const uint32_t r = res[sg.off + i];
+        const bool is_short = (ww.kind[gbase + x] & 0x7Fu) == K_SHORT;
+        const uint32_t fe = (uint32_t)ww.tbits[gbase + x] | ((uint32_t)ww.exitoff[gbase + x] << 16);
+        const int nbf = is_short ? LZSS_SHORT_ADDR_BITS : LZSS_DYN_ADDR_BITS;
+        const uint32_t f = is_short ? (resolve_field(S, r, i, true) & 0x3FFFu) : pending_dyn_field(S, D, r, i);
+        const uint32_t bp = fe - (uint32_t)nbf;                                  // first bit of the field
+        const uint64_t y = (uint64_t)f << (64 - nbf - (int)(bp & 7u));           // byte (bp >> 3) is y's top byte
+        uint8_t *pb = outp + (bp >> 3);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // 21 bits behind up to 7 lead bits: at most 4 bytes
+            const uint32_t byte = (uint32_t)(y >> (56 - 8 * t)) & 0xFFu;
+            if (byte) {
+                const uintptr_t ad = (uintptr_t)(pb + t);
+                atomicOr(reinterpret_cast<uint32_t *>(ad & ~(uintptr_t)3), byte << (8 * (ad & 3)));
+            }
+        }
+    }
+}
+
 void launch_emit(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const uint32_t *d_res, const BatchIndex &ix,
                  const DictView &dict, const WalkWork &ww,
                  uint32_t header_bytes, uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                  uint8_t *d_out, uint64_t out_cap, int32_t *d_status, hipStream_t stream) {
     if (n_segs == 0) return;
     const uint32_t gx = std::max<uint32_t>(1u, (max_n + TILE - 1) / TILE);  // tiles per segment; tile 0 also reports the status
+    const int split = max_n <= RESOLVE_MAX_N ? 1 : 0;
     hipLaunchKernelGGL(emit_kernel, dim3(xcd_grid((uint64_t)gx * n_segs)), dim3(64), 0, stream, d_segs, n_segs, gx, d_text, d_res,
-                       ix, dict, ww, header_bytes, bit_off, dict_len, res_idx_fe, res_idx_ff, d_out, out_cap, d_status);
+                       ix, dict, ww, header_bytes, bit_off, dict_len, res_idx_fe, res_idx_ff, d_out, out_cap, d_status, split);
+    if (split && max_n > 0) {
+        const uint32_t gr = (max_n + RESOLVE_CHUNK - 1) / RESOLVE_CHUNK;
+        hipLaunchKernelGGL(resolve_kernel, dim3(xcd_grid((uint64_t)gr * n_segs)), dim3(RESOLVE_THREADS), 0, stream, d_segs, n_segs, gr,
+                           d_res, ix, dict, ww, header_bytes, d_out, out_cap);
+    }
 }
 
 }  // namespace lzss
