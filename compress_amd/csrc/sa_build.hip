@@ -664,7 +664,7 @@ __device__ inline void scatter_pass(const SaLds<DB> &L, const uint64_t *in, uint
 #ifndef SA_FIN_G
 #define SA_FIN_G 5   // 1: no finishing; at most 8 (measured: 4 82.0, 5 81.0, 6 81.0, 8 92.3 ms per 10 000 blobs)
 #endif
-static_assert(SA_FIN_G <= 8, "seven lists");  // (entries that also carry the members' positions, so that sa_finish
+static_assert(SA_FIN_G <= 6, "finish_group is instantiated for 2 .. 6 members");  // (entries that also carry the members' positions, so that sa_finish
 // need not read them back from the suffix array, cost more in the regroup sweep than they saved: 83.3 vs 80.9 ms)
 // first entry of the list of the groups of z suffixes: a text of N suffixes has at most N / z of them (all lists
 // together, sizes 2 .. 8: 1.72 N four-byte entries - they fit the spare 8-byte-per-suffix record buffer)
@@ -873,6 +873,91 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
 // The listed groups (sa_regroup), one lane each: order the members by direct comparison; a group whose pairs are all
 // decided gets its final slots, leaves the active set and the next round's digit counts.  Returns the number of
 // suffixes finished.  d0: symbols the members of a group are known to share.
+// One listed group of Z suffixes, ordered by one lane.  The members' texts are read ONCE per 32-byte block (all loads
+// of a block in flight together) and every pair is compared from registers; a pair is settled by the first byte that
+// differs, or by length when the shorter suffix ends first (the sentinel is the smallest symbol).  The round trips of
+// a group are then those of its slowest pair, whatever Z - comparing the pairs one after the other made a group of
+// five cost ten chains of dependent loads.  Returns false when a pair is still equal `span` bytes past d0.
+#ifndef SA_FIN_SHARED
+#define SA_FIN_SHARED 1
+#endif
+template <int Z>
+__device__ inline bool finish_group(const uint8_t *T, uint32_t n, const uint32_t *p, int d0, int span, int *place) {
+    constexpr int NP = Z * (Z - 1) / 2;
+    int mo[NP];  // per pair: offset of the first difference (>= the shorter length: settled by length), -1 = not yet known
+    int rest[Z];
+#pragma unroll
+    for (int j = 0; j < Z; ++j) rest[j] = (int)(n - p[j]);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) mo[q] = -1;
+    const int cap = d0 + span;
+    int o = d0;
+    bool open = true;
+    while (open && o < cap) {
+        uint64_t w[Z][4];
+#pragma unroll
+        for (int j = 0; j < Z; ++j) {
+            const int oj = o < rest[j] ? o : rest[j];  // past its end a suffix's pairs are settled: read the padding
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[j][t] = ld8(T + p[j] + oj + 8 * t);
+        }
+        open = false;
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < Z; ++i)
+#pragma unroll
+            for (int j = i + 1; j < Z; ++j, ++q) {
+                if (mo[q] >= 0) continue;
+                const int lim = rest[i] < rest[j] ? rest[i] : rest[j];
+                const uint64_t x0 = w[i][0] ^ w[j][0], x1 = w[i][1] ^ w[j][1], x2 = w[i][2] ^ w[j][2], x3 = w[i][3] ^ w[j][3];
+                int m = -1;
+                if (x0) m = o + (int)(__builtin_ctzll(x0) >> 3);
+                else if (x1) m = o + 8 + (int)(__builtin_ctzll(x1) >> 3);
+                else if (x2) m = o + 16 + (int)(__builtin_ctzll(x2) >> 3);
+                else if (x3) m = o + 24 + (int)(__builtin_ctzll(x3) >> 3);
+                else if (o + 32 >= lim) m = lim;
+                mo[q] = m;
+                open = open || m < 0;
+            }
+        o += 32;
+    }
+    if (open) return false;
+    // settle the pairs: by length, or by the two bytes at the difference (plain loads after the loop: see the note in
+    // match.hip, dict_search_in); all pairs' loads are in flight together
+    int ca[NP], cb[NP];
+    {
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < Z; ++i)
+#pragma unroll
+            for (int j = i + 1; j < Z; ++j, ++q) {
+                const int lim = rest[i] < rest[j] ? rest[i] : rest[j];
+                const int at = mo[q] < lim ? mo[q] : 0;
+                ca[q] = T[p[i] + at];
+                cb[q] = T[p[j] + at];
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < Z; ++j) place[j] = 0;
+    {
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < Z; ++i)
+#pragma unroll
+            for (int j = i + 1; j < Z; ++j, ++q) {
+                const int lim = rest[i] < rest[j] ? rest[i] : rest[j];
+                // i's suffix is the larger one: it is the longer one when the shorter ended, else its byte is larger
+                const bool i_larger = mo[q] >= lim ? p[i] < p[j] : ca[q] > cb[q];
+                if (i_larger) ++place[i];
+                else ++place[j];
+            }
+    }
+    return true;
+}
+
+// The listed groups (sa_regroup), one lane each: order the members by direct comparison; a group whose pairs are all
+// decided gets its final slots, leaves the active set and the next round's digit counts.  Returns the number of
+// suffixes finished.  d0: symbols the members of a group are known to share.
 template <int DB>
 __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint32_t *fin_list, uint32_t fin_N, int32_t *sa,
                                      int32_t *rk, const uint8_t *T, uint32_t n, int d0, int tid) {
@@ -888,6 +973,15 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
 #pragma unroll
             for (int j = 0; j < z; ++j) p[j] = (uint32_t)sa[slot0 + j] & 0x7FFFFFFFu;
             int place[SA_FIN_G];
+#if SA_FIN_SHARED
+            bool ok = false;
+            if (z == 2) ok = finish_group<2>(T, n, p, d0, SA_FIN_SPAN, place);
+            else if (z == 3) ok = finish_group<3>(T, n, p, d0, SA_FIN_SPAN, place);
+            else if (z == 4) ok = finish_group<(SA_FIN_G >= 4 ? 4 : 2)>(T, n, p, d0, SA_FIN_SPAN, place);
+            else if (z == 5) ok = finish_group<(SA_FIN_G >= 5 ? 5 : 2)>(T, n, p, d0, SA_FIN_SPAN, place);
+            else if (z == 6) ok = finish_group<(SA_FIN_G >= 6 ? 6 : 2)>(T, n, p, d0, SA_FIN_SPAN, place);
+            if (!ok) continue;
+#else
 #pragma unroll
             for (int j = 0; j < z; ++j) place[j] = 0;
             bool und = false;
@@ -901,6 +995,7 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
                     else ++place[j];
                 }
             if (und) continue;
+#endif
 #pragma unroll
             for (int j = 0; j < z; ++j) {
                 const uint32_t slot = slot0 + (uint32_t)place[j];
