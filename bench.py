@@ -115,8 +115,14 @@ def main():
     nproc = max(1, min(16, os.cpu_count() or 1, len(ids) // 64))
     if nproc > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(nproc) as pool:
+        # close + join, not the context manager's terminate(): under rocprofv3 every worker carries the profiler's
+        # SIGTERM handler, which can hang in its finalisation and stall the whole run
+        pool = mp.get_context("fork").Pool(nproc)
+        try:
             blobs = pool.starmap(synth.blob, [(b, args.blob_size) for b in ids], chunksize=32)
+        finally:
+            pool.close()
+            pool.join()
     else:
         blobs = [synth.blob(b, args.blob_size) for b in ids]
     t_gen = time.perf_counter() - t_gen
