@@ -218,6 +218,7 @@ static BatchIndex batch_index(mi355_lzss_batch *b) {
     ix.dlb = b->dlb.as<int32_t>();
     ix.cdir = b->cdir.as<uint16_t>();
     ix.nch = std::max<uint32_t>(1, (b->max_n + LZSS_SHORT_WINDOW - 1) / LZSS_SHORT_WINDOW);
+    ix.win_packed = (uint64_t)b->max_n + 1 <= (1u << 18) ? 1u : 0u;
     return ix;
 }
 static WalkWork walk_work(mi355_lzss_batch *b) {

@@ -56,6 +56,9 @@ struct BatchIndex {   // batch-wide index arrays
     // entry of a chunk with rank >= lo is a few entries past cdir[(lo - 1) / 64] instead of a binary search away
     uint16_t *cdir;
     uint32_t nch;     // chunks per segment the directory is laid out for (>= chunks of the largest segment)
+    // texts of up to 2^18 suffixes: an entry of the window index is ONE word, rank << 14 | position inside its chunk
+    // (in ks; ps is not written), which halves what window_index_kernel writes and what the summaries read
+    uint32_t win_packed;
 };
 void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream);
 void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream);

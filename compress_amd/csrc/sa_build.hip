@@ -1381,8 +1381,11 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
         const int rank = __popcll(peers & lanemask_lt(lane));
         const int base = hrow[c];
         if (active) {
-            KS[base + rank] = (int)k;
-            PS[base + rank] = p;
+            if (ix.win_packed) KS[base + rank] = (int)((k << WIN_SHIFT) | ((uint32_t)p & ((1u << WIN_SHIFT) - 1u)));
+            else {
+                KS[base + rank] = (int)k;
+                PS[base + rank] = p;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (active && rank == cnt - 1) hrow[c] = base + cnt;
@@ -1418,7 +1421,7 @@ __global__ __launch_bounds__(256) void block64_kernel(const Seg *segs, const int
 __global__ __launch_bounds__(256) void block64_minmax_kernel(const Seg *segs, BatchIndex ix, int level) {
     const Seg sg = segs[blockIdx.y];
     uint32_t count = sg.n;
-    const int32_t *imin = ix.ps(sg), *imax = imin;
+    const int32_t *imin = ix.win_packed ? ix.ks(sg) : ix.ps(sg), *imax = imin;
     int32_t *omin = ix.pmin1, *omax = ix.pmax1;
     if (level == 1) {
         count = (count + 63) / 64;
@@ -1433,6 +1436,7 @@ __global__ __launch_bounds__(256) void block64_minmax_kernel(const Seg *segs, Ba
     if (j < count) {
         lo = imin[j];
         hi = imax[j];
+        if (level == 0 && ix.win_packed) lo = hi = lo & ((1 << WIN_SHIFT) - 1);  // position inside the chunk
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -18,12 +18,13 @@ namespace lzss {
 // first j in [j0, end) with P[j] < x (LESS) or P[j] >= x (!LESS); `end` if there is none.  m1 / m2 hold the
 // min (LESS) or max (!LESS) of P over blocks of 64 and 4096 entries, so whole blocks without a hit are
 // skipped: at most ~64 steps per level whatever the distance.
+// mask: the bits of an entry of P that hold the value (all for plain arrays; the summaries are over masked values)
 template <bool LESS>
-__device__ inline int next_thr(const int32_t *P, const int32_t *m1, const int32_t *m2, int j0, int end, int x) {
+__device__ inline int next_thr(const int32_t *P, const int32_t *m1, const int32_t *m2, int j0, int end, int x, int mask = -1) {
     int j = j0;
     // rest of the current 64-block, four entries per load once j is a multiple of 4
     while (j < end && (j & 3)) {
-        const int v = P[j];
+        const int v = P[j] & mask;
         if (LESS ? v < x : v >= x) return j;
         ++j;
     }
@@ -31,7 +32,7 @@ __device__ inline int next_thr(const int32_t *P, const int32_t *m1, const int32_
         const I4 q = ld_i4(P + j);  // entries past `end` belong to the padded allocation and are ignored
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            if (j + t < end && (LESS ? q.v[t] < x : q.v[t] >= x)) return j + t;
+            if (j + t < end && (LESS ? (q.v[t] & mask) < x : (q.v[t] & mask) >= x)) return j + t;
         j += 4;
     }
     if (j >= end) return end;
@@ -60,7 +61,7 @@ __device__ inline int next_thr(const int32_t *P, const int32_t *m1, const int32_
         const I4 q = ld_i4(P + j);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            if (j + t < end && (LESS ? q.v[t] < x : q.v[t] >= x)) return j + t;
+            if (j + t < end && (LESS ? (q.v[t] & mask) < x : (q.v[t] & mask) >= x)) return j + t;
     }
     return end;
 }
@@ -72,6 +73,7 @@ struct SegIndex {  // one segment's view of BatchIndex
     const uint16_t *cdir;
     int nch;
     int n;
+    int wsh;  // 14 when the window index is packed (an entry of KS = rank << 14 | position inside the chunk; PS == KS), else 0
 };
 
 #ifndef MATCH_LINEAR_SPAN
@@ -81,16 +83,16 @@ constexpr int LINEAR_SPAN = MATCH_LINEAR_SPAN;  // intervals up to this many ran
 
 // first entry j in [a, end) of a chunk's rank-ordered list with KS[j] >= lo, a coming from the chunk directory
 // (so at most 64 entries away, a chunk's share of 64 ranks)
-__device__ inline int chunk_lower_bound(const int32_t *KS, int a, int end, int lo) {
+__device__ inline int chunk_lower_bound(const int32_t *KS, int a, int end, int lo, int sh) {
     while (a < end && (a & 3)) {
-        if (KS[a] >= lo) return a;
+        if ((int)((uint32_t)KS[a] >> sh) >= lo) return a;
         ++a;
     }
     while (a < end) {
         const I4 q = ld_i4(KS + a);  // entries past `end` belong to the padded allocation and are ignored
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            if (a + t >= end || q.v[t] >= lo) return (a + t < end) ? a + t : end;
+            if (a + t >= end || (int)((uint32_t)q.v[t] >> sh) >= lo) return (a + t < end) ? a + t : end;
         a += 4;
     }
     return end;
@@ -134,19 +136,20 @@ __device__ inline int leftmost(const SegIndex &S, int kdn, int L, int ws, int i,
         const int c2 = (i - 1) >> LZSS_SHORT_ADDR_BITS;  // chunk of the window's last position: entries with pos < i
         const int lo1 = lo < 1 ? 1 : lo;                 // rank 0 is the sentinel, in no chunk
         const uint16_t *dir = S.cdir + (size_t)((lo1 - 1) >> 6) * S.nch;
+        const int pm = S.wsh ? (1 << LZSS_SHORT_ADDR_BITS) - 1 : -1;  // packed: positions are relative to their chunk
         {
             const int beg = c2 << LZSS_SHORT_ADDR_BITS;
             const int end = (beg + LZSS_SHORT_WINDOW) < S.n ? (beg + LZSS_SHORT_WINDOW) : S.n;
-            const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2], end, lo1);
-            const int j = next_thr<true>(S.PS, S.pmin1, S.pmin2, a, end, i);
-            if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
+            const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2], end, lo1, S.wsh);
+            const int j = next_thr<true>(S.PS, S.pmin1, S.pmin2, a, end, S.wsh ? i - beg : i, pm);
+            if (j < end) { const int k = (int)((uint32_t)S.KS[j] >> S.wsh); best = k < best ? k : best; }
         }
         if (c2 >= 1 && ws < (c2 << LZSS_SHORT_ADDR_BITS)) {  // previous chunk: entries with pos >= ws
             const int beg = (c2 - 1) << LZSS_SHORT_ADDR_BITS;
             const int end = beg + LZSS_SHORT_WINDOW;
-            const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2 - 1], end, lo1);
-            const int j = next_thr<false>(S.PS, S.pmax1, S.pmax2, a, end, ws);
-            if (j < end) { const int k = S.KS[j]; best = k < best ? k : best; }
+            const int a = chunk_lower_bound(S.KS, beg + (int)dir[c2 - 1], end, lo1, S.wsh);
+            const int j = next_thr<false>(S.PS, S.pmax1, S.pmax2, a, end, S.wsh ? ws - beg : ws, pm);
+            if (j < end) { const int k = (int)((uint32_t)S.KS[j] >> S.wsh); best = k < best ? k : best; }
         }
         res = S.SA[best];
         MP(10)
@@ -163,7 +166,8 @@ __device__ inline SegIndex seg_index(const BatchIndex &ix, const Seg &sg) {
     SegIndex S;
     S.SA = ix.sa + sg.off; S.LCP = ix.lcp + sg.off;
     S.b1 = ix.bmin1 + sg.off / 64; S.b2 = ix.bmin2 + sg.off / 64;
-    S.KS = ix.ks(sg); S.PS = ix.ps(sg);
+    S.KS = ix.ks(sg); S.PS = ix.win_packed ? ix.ks(sg) : ix.ps(sg);
+    S.wsh = ix.win_packed ? LZSS_SHORT_ADDR_BITS : 0;
     S.pmin1 = ix.pmin1 + sg.off / 64; S.pmax1 = ix.pmax1 + sg.off / 64;
     S.pmin2 = ix.pmin2 + sg.off / 64; S.pmax2 = ix.pmax2 + sg.off / 64;
     S.samin1 = ix.samin1 + sg.off / 64; S.samin2 = ix.samin2 + sg.off / 64;
