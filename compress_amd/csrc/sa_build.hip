@@ -1391,6 +1391,48 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
         if (active && rank == cnt - 1) hrow[c] = base + cnt;
         __builtin_amdgcn_wave_barrier();
     }
+    // min / max of the positions over blocks of 64 and of 4096 entries, from the entries this workgroup has just
+    // written (they are still in its L2): a wave per block of 64, then a wave per 64 summaries
+    __syncthreads();
+    const int32_t *E = ix.win_packed ? KS : PS;
+    const int emask = ix.win_packed ? (1 << WIN_SHIFT) - 1 : -1;
+    int32_t *pmin1 = ix.pmin1 + sg.off / 64, *pmax1 = ix.pmax1 + sg.off / 64;
+    int32_t *pmin2 = ix.pmin2 + sg.off / 64, *pmax2 = ix.pmax2 + sg.off / 64;
+    const uint32_t nb1 = (n + 63) / 64, nb2 = (nb1 + 63) / 64;
+    for (uint32_t b = w; b < nb1; b += SA_WAVES) {
+        const uint32_t j = b * 64 + lane;
+        int lo = INT_MAX, hi = INT_MIN;
+        if (j < n) lo = hi = E[j] & emask;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int x = __shfl_xor(lo, o), y = __shfl_xor(hi, o);
+            lo = x < lo ? x : lo;
+            hi = y > hi ? y : hi;
+        }
+        if (lane == 0) {
+            pmin1[b] = lo;
+            pmax1[b] = hi;
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = w; b < nb2; b += SA_WAVES) {
+        const uint32_t j = b * 64 + lane;
+        int lo = INT_MAX, hi = INT_MIN;
+        if (j < nb1) {
+            lo = pmin1[j];
+            hi = pmax1[j];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int x = __shfl_xor(lo, o), y = __shfl_xor(hi, o);
+            lo = x < lo ? x : lo;
+            hi = y > hi ? y : hi;
+        }
+        if (lane == 0) {
+            pmin2[b] = lo;
+            pmax2[b] = hi;
+        }
+    }
 }
 
 // min / max over blocks of 64 entries of a per-segment int32 array with `count(seg)` entries
@@ -1416,47 +1458,11 @@ __global__ __launch_bounds__(256) void block64_kernel(const Seg *segs, const int
     if ((threadIdx.x & 63) == 0) out[sg.off / 64 + (j >> 6)] = v;
 }
 
-// min and max over blocks of 64 entries.  level 0: of the positions of the window index (n entries per segment);
-// level 1: of the level-0 minima / maxima ([off/64 + j], ceil(n / 64) entries)
-__global__ __launch_bounds__(256) void block64_minmax_kernel(const Seg *segs, BatchIndex ix, int level) {
-    const Seg sg = segs[blockIdx.y];
-    uint32_t count = sg.n;
-    const int32_t *imin = ix.win_packed ? ix.ks(sg) : ix.ps(sg), *imax = imin;
-    int32_t *omin = ix.pmin1, *omax = ix.pmax1;
-    if (level == 1) {
-        count = (count + 63) / 64;
-        imin = ix.pmin1 + sg.off / 64;
-        imax = ix.pmax1 + sg.off / 64;
-        omin = ix.pmin2;
-        omax = ix.pmax2;
-    }
-    if (blockIdx.x * 256 >= count) return;
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    int lo = INT_MAX, hi = INT_MIN;
-    if (j < count) {
-        lo = imin[j];
-        hi = imax[j];
-        if (level == 0 && ix.win_packed) lo = hi = lo & ((1 << WIN_SHIFT) - 1);  // position inside the chunk
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
-        lo = a < lo ? a : lo;
-        hi = b > hi ? b : hi;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        omin[sg.off / 64 + (j >> 6)] = lo;
-        omax[sg.off / 64 + (j >> 6)] = hi;
-    }
-}
-
 void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream) {
     if (n_segs == 0 || max_n == 0) return;
     hipLaunchKernelGGL(window_index_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, ix);
     const uint32_t c0 = max_n + 1, c1 = (c0 + 63) / 64;
-    dim3 g0((c0 + 255) / 256, n_segs), g1((c1 + 255) / 256, n_segs);
-    hipLaunchKernelGGL(block64_minmax_kernel, g0, dim3(256), 0, stream, d_segs, ix, 0);
-    hipLaunchKernelGGL(block64_minmax_kernel, g1, dim3(256), 0, stream, d_segs, ix, 1);
+    dim3 g1((c1 + 255) / 256, n_segs);
     hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.samin1, ix.samin2, 1, 1);  // samin1: lcp_kernel
 }
 
