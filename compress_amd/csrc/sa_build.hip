@@ -369,7 +369,7 @@ template <int DB> struct SaInit {
 #ifdef SA_PROFILE  // per-phase clocks of workgroup 0 (debug builds only)
 #define SA_PROF_DECL long long prof_acc[20] = {}; long long prof_last = clock64();
 #define SA_PROF(i) { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); prof_acc[i] += t_ - prof_last; prof_last = t_; }
-#define SA_PROF_PRINT if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x / 64 < 2) { printf("w%d init: ld %lld rank %lld prep %lld put %lld | regI %lld | S1: ld %lld gath %lld rank %lld prep %lld put %lld | S2: ld %lld rank %lld prep %lld put %lld | D %lld | other %lld\n", threadIdx.x / 64, prof_acc[0], prof_acc[1], prof_acc[2], prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11], prof_acc[12], prof_acc[13], prof_acc[14], prof_acc[15]); }
+#define SA_PROF_PRINT if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x / 64 < 2) { printf("w%d init: ld %lld rank %lld prep %lld put %lld | regI %lld | S1: ld %lld gath %lld rank %lld prep %lld put %lld | S2: ld %lld rank %lld prep %lld put %lld | D %lld | other %lld | late build %lld passes %lld | finish init %lld rounds %lld\n", threadIdx.x / 64, prof_acc[0], prof_acc[1], prof_acc[2], prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11], prof_acc[12], prof_acc[13], prof_acc[14], prof_acc[15], prof_acc[16], prof_acc[17], prof_acc[19], prof_acc[18]); }
 #else
 #define SA_PROF_DECL
 #define SA_PROF(i)
@@ -1188,14 +1188,15 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
 
     SA_PROF(15)
     uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid, (uint32_t *)(rcur == recA ? recB : recA), N);
-    m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), N, sa, rk, T, n, (int)SaInit<DB>::H0, tid);
     SA_PROF(4)
+    m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), N, sa, rk, T, n, (int)SaInit<DB>::H0, tid);
+    SA_PROF(19)
     uint32_t h = SaInit<DB>::H0;  // every group of the initial keys shares at least that many symbols
-#ifdef SA_PROFILE
+#ifdef SA_PROFILE_ROUNDS  // (a device printf costs far more than a round: not in the clocked build)
     if (blockIdx.x == 0 && tid == 0) printf("after init: N=%u m=%u\n", N, m);
 #endif
     while (m != 0 && h < N && --max_rounds >= 0) {
-#ifdef SA_PROFILE
+#ifdef SA_PROFILE_ROUNDS
         if (blockIdx.x == 0 && tid == 0) printf("round h=%u m=%u late=%d\n", h, m, (int)((uint64_t)m * SA_LATE_DIV <= N));
 #endif
         if ((uint64_t)m * SA_LATE_DIV <= N) {
@@ -1209,26 +1210,51 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             }
             if (tid == 0) cy.wcount[0] = 0;
             __syncthreads();
+            // the active positions first, as a list (in the part of recA the passes below do not reach) ...
+            uint32_t *plist = (uint32_t *)(recA + (N + 1) / 2);
             for (uint32_t x = tid; x < words; x += SAM_THREADS) {
                 uint32_t wbits = L.act[x];
                 if (wbits) {
                     int pos = atomicAdd(&cy.wcount[0], __popc(wbits));
                     while (wbits) {
-                        const uint32_t p = x * 32 + (uint32_t)__builtin_ctz(wbits);
+                        plist[pos++] = x * 32 + (uint32_t)__builtin_ctz(wbits);
                         wbits &= wbits - 1;
-                        const uint32_t k1 = (uint32_t)rk[p];
-                        const uint32_t k2 = (p + h < N) ? (uint32_t)rk[p + h] : 0u;
-                        recB[pos++] = ((uint64_t)k1 << 40) | ((uint64_t)k2 << 20) | (uint64_t)p;
-                        atomicAdd(&hx[k2 & MASK], 1);
-                        atomicAdd(&L.hy[k2 >> DB], 1);
                     }
                 }
             }
             __syncthreads();
+            // ... then one record per list entry: the two rank gathers of an entry depend on nothing but the list, so
+            // a thread has those of several entries in flight (gathering inside the bit loop above made every entry
+            // wait for the one before: 26 % of the kernel for 5 % of the suffixes)
+            for (uint32_t q0 = tid; q0 < m; q0 += 4 * SAM_THREADS) {
+                uint32_t p[4], k1[4], k2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t q = q0 + (uint32_t)u * SAM_THREADS;
+                    p[u] = q < m ? plist[q] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    k1[u] = (uint32_t)rk[p[u]];
+                    k2[u] = (p[u] + h < N) ? (uint32_t)rk[p[u] + h] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t q = q0 + (uint32_t)u * SAM_THREADS;
+                    if (q < m) {
+                        recB[q] = ((uint64_t)k1[u] << 40) | ((uint64_t)k2[u] << 20) | (uint64_t)p[u];
+                        atomicAdd(&hx[k2[u] & MASK], 1);
+                        atomicAdd(&L.hy[k2[u] >> DB], 1);
+                    }
+                }
+            }
+            __syncthreads();
+            SA_PROF(16)
             scatter_pass<DB>(L, recB, recA, m, 20, hx, tid);
             scatter_pass<DB>(L, recA, recB, m, 20 + DB, L.hy, tid);
             scatter_pass<DB>(L, recB, recA, m, 40, L.hl, tid);
             scatter_pass<DB>(L, recA, recB, m, 40 + DB, L.hh, tid);
+            SA_PROF(17)
         } else {
         // ---- S1: active members of the sequence p = SA[j] - h -> records, scattered by the low digit of k1
         bins_scan(L.hl, L.base, NB, tid);
@@ -1313,8 +1339,9 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         __syncthreads();
         // ---- D: new groups
         m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid, (uint32_t *)recA, N);
-        m -= sa_finish<DB>(L, cy, (const uint32_t *)recA, N, sa, rk, T, n, (int)(2 * h < (1u << 20) ? 2 * h : (1u << 20)), tid);
         SA_PROF(14)
+        m -= sa_finish<DB>(L, cy, (const uint32_t *)recA, N, sa, rk, T, n, (int)(2 * h < (1u << 20) ? 2 * h : (1u << 20)), tid);
+        SA_PROF(18)
         h *= 2;
     }
     if (m != 0) {  // rounds cut short (timing experiments): drop the group marks so that SA stays a permutation
