@@ -203,6 +203,7 @@ static SaWork sa_work(mi355_lzss_batch *b) {
     w.flags = b->flags.as<uint8_t>();
     w.rlen = b->rlen.as<uint8_t>();
     w.sa = b->sa.as<int32_t>(); w.isa = b->isa.as<int32_t>();
+    w.pairs = b->res.as<uint32_t>();
     return w;
 }
 static BatchIndex batch_index(mi355_lzss_batch *b) {

@@ -12,6 +12,8 @@ struct SaWork {       // batch-wide arrays, indexed [seg.off + k], k in [0, n]
     uint8_t *flags;                      // group-boundary flags
     int32_t *sa, *isa;                   // outputs
     uint8_t *rlen;                       // output: length of the run of equal bytes starting at every position, capped at 255
+    uint32_t *pairs;                     // scratch of the main kernel, 4 bytes per suffix ([seg.off + k]; the match results'
+                                         // buffer, which nothing uses before the segment is sorted)
 };
 // texts of more than this many suffixes are sorted by the fallback kernel, which uses the sort buffers as whole-batch
 // int32 arrays: no other stage of the batch may run beside it

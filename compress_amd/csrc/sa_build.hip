@@ -367,9 +367,9 @@ template <int DB> struct SaInit {
 #define SA_USE_MTAB 1
 #endif
 #ifdef SA_PROFILE  // per-phase clocks of workgroup 0 (debug builds only)
-#define SA_PROF_DECL long long prof_acc[20] = {}; long long prof_last = clock64();
+#define SA_PROF_DECL long long prof_acc[24] = {}; long long prof_last = clock64();
 #define SA_PROF(i) { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); prof_acc[i] += t_ - prof_last; prof_last = t_; }
-#define SA_PROF_PRINT if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x / 64 < 2) { printf("w%d init: ld %lld rank %lld prep %lld put %lld | regI %lld | S1: ld %lld gath %lld rank %lld prep %lld put %lld | S2: ld %lld rank %lld prep %lld put %lld | D %lld | other %lld | late build %lld passes %lld | finish init %lld rounds %lld\n", threadIdx.x / 64, prof_acc[0], prof_acc[1], prof_acc[2], prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11], prof_acc[12], prof_acc[13], prof_acc[14], prof_acc[15], prof_acc[16], prof_acc[17], prof_acc[19], prof_acc[18]); }
+#define SA_PROF_PRINT if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x / 64 < 2) { printf("w%d init: ld %lld rank %lld prep %lld put %lld | regI %lld | S1: ld %lld gath %lld rank %lld prep %lld put %lld | S2: ld %lld rank %lld prep %lld put %lld | D %lld | other %lld | late build %lld passes %lld | finish init %lld rounds %lld | setup %lld sweep %lld\n", threadIdx.x / 64, prof_acc[0], prof_acc[1], prof_acc[2], prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11], prof_acc[12], prof_acc[13], prof_acc[14], prof_acc[15], prof_acc[16], prof_acc[17], prof_acc[19], prof_acc[18], prof_acc[20], prof_acc[21]); }
 #else
 #define SA_PROF_DECL
 #define SA_PROF(i)
@@ -390,6 +390,18 @@ constexpr int SA_K = SA_MAIN_K;  // sequence entries per thread and tile
 constexpr int SA_WSPAN = 64 * SA_K;            // consecutive entries of one wave inside a tile
 constexpr int SA_TILE = SAM_THREADS * SA_K;
 
+#ifndef SA_SWEEP_AHEAD
+#define SA_SWEEP_AHEAD 2   // steps between the loads behind a block's runs and the block's records (key sweep)
+#endif
+#ifndef SA_ISA_BINNED
+#define SA_ISA_BINNED 1
+#endif
+// The initial regroup knows the rank of every suffix in suffix order and has to store it in position order.  Written
+// directly that is one random 4-byte store per suffix, and a random store costs a whole 32-byte sector of HBM write
+// (a third of the kernel's WRITE_SIZE).  Instead the (rank, position) pairs are first appended to one stream per chunk
+// of 8192 positions (4 bytes per pair: rank << 13 | position inside the chunk; a chunk receives exactly 8192 pairs, so
+// the streams need no counting pass), and every chunk is then spread out in LDS and written as one 32 KiB run.
+constexpr int SA_ISA_CH = 13;
 #ifndef SA_LATE_DIVISOR
 #define SA_LATE_DIVISOR 16
 #endif
@@ -490,6 +502,7 @@ struct SaCarry {
     int32_t b[2][SAM_WAVES];
     int32_t wcount[SAM_WAVES];
     int32_t fin_cnt[8];   // small groups listed for sa_finish, by size (2 .. 8 at [0 .. 6]); [7]: suffixes it has finished
+    int32_t bin_cur[64];  // initial regroup: (position, rank) pairs written so far per chunk of 2^SA_ISA_CH positions
 };
 
 // lanes of the wave (among `valid`) holding the same digit as this lane.  The most frequent digits are found
@@ -719,9 +732,12 @@ __device__ inline int suffix_cmp(const uint8_t *T, uint32_t n, uint32_t pa, uint
 // Returns the number of suffixes that still share their group.
 template <bool INITIAL, int DB>
 __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uint64_t *rec, uint32_t m, int32_t *sa,
-                                      int32_t *rk, int tid, uint32_t *fin_list, uint32_t fin_N) {
+                                      int32_t *rk, int tid, uint32_t *fin_list, uint32_t fin_N, uint32_t *pairs = nullptr) {
     constexpr int NB = 1 << DB;
     constexpr int RS = INITIAL ? SaInit<DB>::SHIFT : 20;  // bits of the suffix index below the key(s)
+    // the chunk staging area of the binned rank store: woff and the peer table (both idle here; the table is zeroed again)
+    constexpr size_t STAGE_BYTES = (size_t)SAM_WAVES * NB * 2 + (SA_MTAB ? (size_t)SAM_WAVES * SaLds<DB>::mtab_entries() * 8 : 0);
+    constexpr bool BINNED = INITIAL && SA_ISA_BINNED && STAGE_BYTES >= ((size_t)4 << SA_ISA_CH);
     const int lane = tid & 63, w = tid >> 6;
     int tileK = -1, tileS = -1;
     uint32_t rem = 0;
@@ -841,7 +857,13 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             }
             if (valid) {
                 sa[slot] = p[s] | ((fS && !sgl) ? (int)0x80000000 : 0);  // top bit: first slot of a shared group
-                rk[p[s]] = nr;
+                if (BINNED) {
+                    const uint32_t bin = (uint32_t)p[s] >> SA_ISA_CH;
+                    const uint32_t at = (uint32_t)atomicAdd(&cy.bin_cur[bin], 1);
+                    pairs[(bin << SA_ISA_CH) + at] = ((uint32_t)nr << SA_ISA_CH) | ((uint32_t)p[s] & ((1u << SA_ISA_CH) - 1u));
+                } else {
+                    rk[p[s]] = nr;
+                }
                 if (INITIAL) {
                     if (!sgl) atomicOr(&L.act[(uint32_t)p[s] >> 5], 1u << (p[s] & 31));
                 } else if (sgl) {
@@ -861,6 +883,38 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             }
             rem += (uint32_t)__popcll(__ballot(valid && !sgl));
         }
+    }
+    if (BINNED) {
+        constexpr uint32_t CH = 1u << SA_ISA_CH;
+        constexpr int PER = (int)(CH / SAM_THREADS);
+        uint32_t *stage = reinterpret_cast<uint32_t *>(L.woff);
+        __syncthreads();  // every pair is written
+        for (uint32_t c0 = 0; c0 < m; c0 += CH) {
+            const uint32_t cnt = m - c0 < CH ? m - c0 : CH;
+            uint32_t v[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const uint32_t x = (uint32_t)i * SAM_THREADS + (uint32_t)tid;
+                v[i] = x < cnt ? pairs[c0 + x] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const uint32_t x = (uint32_t)i * SAM_THREADS + (uint32_t)tid;
+                if (x < cnt) stage[v[i] & (CH - 1u)] = v[i] >> SA_ISA_CH;
+            }
+            __syncthreads();
+            for (uint32_t x = (uint32_t)tid * 4; x < cnt; x += SAM_THREADS * 4) {
+                if (x + 4 <= cnt) {
+                    const int2 lo = *reinterpret_cast<const int2 *>(stage + x), hi = *reinterpret_cast<const int2 *>(stage + x + 2);
+                    *reinterpret_cast<int4 *>(rk + c0 + x) = make_int4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                    for (uint32_t y = x; y < cnt; ++y) rk[c0 + y] = (int)stage[y];
+                }
+            }
+            __syncthreads();
+        }
+        if (SA_MTAB)
+            for (int x = tid; x < SAM_WAVES * SaLds<DB>::mtab_entries(); x += SAM_THREADS) L.mtab[x] = 0;
     }
     if (lane == 0) cy.wcount[w] = (int)rem;
     __syncthreads();
@@ -1042,12 +1096,14 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
 
     SA_PROF_DECL
     if (tid < 8) cy.fin_cnt[tid] = 0;
+    if (tid < 64) cy.bin_cur[tid] = 0;
     for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;
     for (int x = tid; x < 6 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh, hy
     for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
     if (SA_MTAB)
         for (int x = tid; x < SAM_WAVES * SaLds<DB>::mtab_entries(); x += SAM_THREADS) L.mtab[x] = 0;
     __syncthreads();
+    SA_PROF(20)
 
     // ---- initial keys.  36 bits per suffix, 4 digits of 9: (first symbol c, run code, x, y) where the run code
     //      encodes the length rl of the run of c the suffix starts with and x, y are the two symbols after the
@@ -1066,72 +1122,112 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         // and only the fifth is new in each step - one two-byte load per lane and step instead of ten byte loads.
         const uint32_t nblk = (N + 63) / 64, per = (nblk + SAM_WAVES - 1) / SAM_WAVES;
         const uint32_t bb = (uint32_t)w * per, be = bb + per < nblk ? bb + per : nblk;
-        auto eq_flags = [&](uint32_t blk) -> uint64_t {
+        // The loads of a step are issued ahead of their use (4 waves per SIMD hide little latency by themselves, and a
+        // step that waited for its flag load and then for the load behind its run took 2.6 us): the flag bytes of a
+        // block arrive two steps before their ballot, and the symbols behind the runs of a block are requested
+        // SA_SWEEP_AHEAD steps before the block's records are built.
+        constexpr int PD = SA_SWEEP_AHEAD;
+        auto raw_load = [&](uint32_t blk) -> uint32_t {
             const uint32_t q = blk * 64 + (uint32_t)lane;
-            bool eq = false;
-            if (q + 1 < n) {
-                uint16_t v;
-                __builtin_memcpy(&v, T + q, 2);
-                eq = (v & 0xFFu) == (v >> 8);
-            }
-            return __ballot(eq);
+            uint16_t v = 0;
+            if (q < N) __builtin_memcpy(&v, T + q, 2);  // (zero padding follows the text)
+            return v;
+        };
+        auto flags_of = [&](uint32_t blk, uint32_t v) -> uint64_t {
+            const uint32_t q = blk * 64 + (uint32_t)lane;
+            return __ballot(q + 1 < n && (v & 0xFFu) == (v >> 8));
         };
         uint64_t E1 = 0, E2 = 0, E3 = 0, E4 = 0;
+        uint32_t rawA = 0, rawB = 0;
         if (bb < be) {
-            E1 = eq_flags(bb);
-            E2 = eq_flags(bb + 1);
-            E3 = eq_flags(bb + 2);
-            E4 = eq_flags(bb + 3);
+            const uint32_t r0 = raw_load(bb), r1 = raw_load(bb + 1), r2 = raw_load(bb + 2), r3 = raw_load(bb + 3);
+            rawA = raw_load(bb + 4);
+            rawB = raw_load(bb + 5);
+            E1 = flags_of(bb, r0);
+            E2 = flags_of(bb + 1, r1);
+            E3 = flags_of(bb + 2, r2);
+            E4 = flags_of(bb + 3, r3);
         }
-        for (uint32_t blk = bb; blk < be; ++blk) {
-            const uint64_t E0 = E1;
-            E1 = E2; E2 = E3; E3 = E4;
-            E4 = eq_flags(blk + 4);
-            const uint32_t e = blk * 64 + (uint32_t)lane;
-            // ones from this lane's flag on (run_length_64 on the sliding flags)
-            const uint64_t x0 = E0 >> lane;
-            int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);
-            if (rl == 64 - lane) {
-                const uint64_t Et[4] = {E1, E2, E3, E4};
+        int p_rl[PD];
+        uint32_t p_v[PD], p_s[PD];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int rt = Et[t] == ~0ull ? 64 : (int)__builtin_ctzll(~Et[t]);
-                    rl += rt;
-                    if (rt < 64) break;
+        for (int t = 0; t < PD; ++t) {
+            p_rl[t] = 1;
+            p_v[t] = p_s[t] = 0;
+        }
+        for (uint32_t c = bb; c < be + PD && bb < be; ++c) {
+            // ---- block c: run lengths from the sliding flags, loads of the symbols behind the runs
+            int n_rl = 1;
+            uint32_t n_v = 0, n_s = 0;
+            if (c < be) {
+                const uint64_t E0 = E1;
+                E1 = E2; E2 = E3; E3 = E4;
+                E4 = flags_of(c + 4, rawA);
+                rawA = rawB;
+                rawB = raw_load(c + 6);
+                const uint32_t e = c * 64 + (uint32_t)lane;
+                // ones from this lane's flag on (run_length_64 on the sliding flags)
+                const uint64_t x0 = E0 >> lane;
+                int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);
+                if (rl == 64 - lane) {
+                    const uint64_t Et[4] = {E1, E2, E3, E4};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int rt = Et[t] == ~0ull ? 64 : (int)__builtin_ctzll(~Et[t]);
+                        rl += rt;
+                        if (rt < 64) break;
+                    }
+                }
+                n_rl = rl + 1;
+                if (e < N) {
+                    n_s = T[e];
+                    if (n_rl < SA_RUN_CAP) __builtin_memcpy(&n_v, T + e + (uint32_t)n_rl, 4);  // (the text is zero padded)
                 }
             }
-            rl += 1;
-            const bool valid = e < N;
-            if (valid) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
-            uint64_t rec = 0;
-            int dZ = 0, dY = 0, dX = 0, dC = 0, dS = 0;
-            if (valid) {
-                dS = e < n ? (int)T[e] + 1 : 0;
-                if (rl >= SA_RUN_CAP) {
-                    dC = 255;
-                } else {
-                    const uint32_t q = e + (uint32_t)rl;  // the symbols after the run, one load (the text is zero padded)
-                    uint32_t v;
-                    __builtin_memcpy(&v, T + q, 4);
-                    dX = q < n ? (int)(v & 0xFFu) + 1 : 0;
-                    dY = q + 1 < n ? (int)((v >> 8) & 0xFFu) + 1 : 0;
-                    dZ = q + 2 < n ? (int)((v >> 16) & 0xFFu) + 1 : 0;
-                    dC = dX < dS ? rl : 511 - rl;
+            // ---- block c - PD: records and digit counts
+            if (c >= bb + PD) {
+                const uint32_t e = (c - PD) * 64 + (uint32_t)lane;
+                const int rl = p_rl[0];
+                const uint32_t v = p_v[0];
+                const bool valid = e < N;
+                if (valid) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
+                int dZ = 0, dY = 0, dX = 0, dC = 0, dS = 0;
+                if (valid) {
+                    dS = e < n ? (int)p_s[0] + 1 : 0;
+                    if (rl >= SA_RUN_CAP) {
+                        dC = 255;
+                    } else {
+                        const uint32_t q = e + (uint32_t)rl;
+                        dX = q < n ? (int)(v & 0xFFu) + 1 : 0;
+                        dY = q + 1 < n ? (int)((v >> 8) & 0xFFu) + 1 : 0;
+                        dZ = q + 2 < n ? (int)((v >> 16) & 0xFFu) + 1 : 0;
+                        dC = dX < dS ? rl : 511 - rl;
+                    }
+                    uint64_t rec = ((((uint64_t)dS << 9) | (uint64_t)dC) << 9) | (uint64_t)dX;
+                    if (SaInit<DB>::DIGITS >= 4) rec = (rec << 9) | (uint64_t)dY;
+                    if (SaInit<DB>::Z) rec = (rec << 9) | (uint64_t)dZ;
+                    rec = (rec << SaInit<DB>::SHIFT) | (uint64_t)e;
+                    recB[e] = rec;
                 }
-                rec = ((((uint64_t)dS << 9) | (uint64_t)dC) << 9) | (uint64_t)dX;
-                if (SaInit<DB>::DIGITS >= 4) rec = (rec << 9) | (uint64_t)dY;
-                if (SaInit<DB>::Z) rec = (rec << 9) | (uint64_t)dZ;
-                rec = (rec << SaInit<DB>::SHIFT) | (uint64_t)e;
-                recB[e] = rec;
+                if (SaInit<DB>::Z) digit_count(hZ, dZ, valid, lane);
+                if (SaInit<DB>::DIGITS >= 4) digit_count(hY, dY, valid, lane);
+                digit_count(hX, dX, valid, lane);
+                digit_count(hC, dC, valid, lane);
+                digit_count(hS, dS, valid, lane);
             }
-            if (SaInit<DB>::Z) digit_count(hZ, dZ, valid, lane);
-            if (SaInit<DB>::DIGITS >= 4) digit_count(hY, dY, valid, lane);
-            digit_count(hX, dX, valid, lane);
-            digit_count(hC, dC, valid, lane);
-            digit_count(hS, dS, valid, lane);
+#pragma unroll
+            for (int t = 0; t + 1 < PD; ++t) {
+                p_rl[t] = p_rl[t + 1];
+                p_v[t] = p_v[t + 1];
+                p_s[t] = p_s[t + 1];
+            }
+            p_rl[PD - 1] = n_rl;
+            p_v[PD - 1] = n_v;
+            p_s[PD - 1] = n_s;
         }
     }
     __syncthreads();
+    SA_PROF(21)
 
     // ---- initial order: 4 LSD passes over the records, least significant digit (y) first
     {
@@ -1187,7 +1283,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     __syncthreads();
 
     SA_PROF(15)
-    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid, (uint32_t *)(rcur == recA ? recB : recA), N);
+    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid, (uint32_t *)(rcur == recA ? recB : recA), N, wk.pairs + sg.off);
     SA_PROF(4)
     m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), N, sa, rk, T, n, (int)SaInit<DB>::H0, tid);
     SA_PROF(19)
