@@ -393,6 +393,12 @@ constexpr int SA_TILE = SAM_THREADS * SA_K;
 #ifndef SA_SWEEP_AHEAD
 #define SA_SWEEP_AHEAD 2   // steps between the loads behind a block's runs and the block's records (key sweep)
 #endif
+#ifndef SA_PEER_ROUNDS
+#define SA_PEER_ROUNDS 1    // leader votes of wave_peers before the bit table
+#endif
+#ifndef SA_COUNT_ROUNDS
+#define SA_COUNT_ROUNDS 1   // leader votes of digit_count before the per-lane atomics
+#endif
 #ifndef SA_ISA_BINNED
 #define SA_ISA_BINNED 1
 #endif
@@ -403,7 +409,7 @@ constexpr int SA_TILE = SAM_THREADS * SA_K;
 // the streams need no counting pass), and every chunk is then spread out in LDS and written as one 32 KiB run.
 constexpr int SA_ISA_CH = 13;
 #ifndef SA_LATE_DIVISOR
-#define SA_LATE_DIVISOR 16
+#define SA_LATE_DIVISOR 4
 #endif
 constexpr uint32_t SA_LATE_DIV = SA_LATE_DIVISOR;  // rounds with at most N / this active suffixes skip the sweep
 constexpr int SA_RUN_CAP = 254;  // runs of equal symbols are told apart by length up to here
@@ -513,7 +519,7 @@ __device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lan
     uint64_t peers = 0;
     bool todo = valid;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < SA_PEER_ROUNDS; ++r) {
         const uint64_t rem = __ballot(todo);
         if (rem) {
             const int dl = __shfl(d, (int)__builtin_ctzll(rem));
@@ -604,7 +610,7 @@ __device__ inline void tile_put(const SaLds<DB> &L, uint64_t *out, int d, int w,
 __device__ inline void digit_count(int32_t *hist, int d, bool valid, int lane) {
     bool todo = valid;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < SA_COUNT_ROUNDS; ++r) {
         const uint64_t rem = __ballot(todo);
         if (rem) {
             const int first = (int)__builtin_ctzll(rem);
@@ -936,7 +942,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
 #define SA_FIN_SHARED 1
 #endif
 template <int Z>
-__device__ inline bool finish_group(const uint8_t *T, uint32_t n, const uint32_t *p, int d0, int span, int *place) {
+__device__ inline int finish_group(const uint8_t *T, uint32_t n, const uint32_t *p, int d0, int span, int *place) {
     constexpr int NP = Z * (Z - 1) / 2;
     int mo[NP];  // per pair: offset of the first difference (>= the shorter length: settled by length), -1 = not yet known
     int rest[Z];
@@ -975,7 +981,12 @@ __device__ inline bool finish_group(const uint8_t *T, uint32_t n, const uint32_t
             }
         o += 32;
     }
-    if (open) return false;
+    if (open) {  // 2: no pair is decided - the members share their first d0 + span symbols
+        bool none = true;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) none = none && mo[q] < 0;
+        return none ? 2 : 0;
+    }
     // settle the pairs: by length, or by the two bytes at the difference (plain loads after the loop: see the note in
     // match.hip, dict_search_in); all pairs' loads are in flight together
     int ca[NP], cb[NP];
@@ -1028,13 +1039,16 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
             for (int j = 0; j < z; ++j) p[j] = (uint32_t)sa[slot0 + j] & 0x7FFFFFFFu;
             int place[SA_FIN_G];
 #if SA_FIN_SHARED
-            bool ok = false;
+            int ok = 0;
             if (z == 2) ok = finish_group<2>(T, n, p, d0, SA_FIN_SPAN, place);
             else if (z == 3) ok = finish_group<3>(T, n, p, d0, SA_FIN_SPAN, place);
             else if (z == 4) ok = finish_group<(SA_FIN_G >= 4 ? 4 : 2)>(T, n, p, d0, SA_FIN_SPAN, place);
             else if (z == 5) ok = finish_group<(SA_FIN_G >= 5 ? 5 : 2)>(T, n, p, d0, SA_FIN_SPAN, place);
             else if (z == 6) ok = finish_group<(SA_FIN_G >= 6 ? 6 : 2)>(T, n, p, d0, SA_FIN_SPAN, place);
-            if (!ok) continue;
+#ifdef SA_PROFILE_ROUNDS
+            if (ok != 1) atomicAdd(&cy.fin_cnt[ok == 2 ? 6 : 5], z);
+#endif
+            if (ok != 1) continue;
 #else
 #pragma unroll
             for (int j = 0; j < z; ++j) place[j] = 0;
@@ -1064,6 +1078,9 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
     }
     __syncthreads();
     const uint32_t done = (uint32_t)cy.fin_cnt[7];
+#ifdef SA_PROFILE_ROUNDS
+    if (blockIdx.x == 0 && tid == 0) printf("  finish d0=%d: listed groups %d %d %d %d, finished %u, failed with a decided pair %d, failed all equal %d\n", d0, cy.fin_cnt[0], cy.fin_cnt[1], cy.fin_cnt[2], cy.fin_cnt[3], done, cy.fin_cnt[5], cy.fin_cnt[6]);
+#endif
     __syncthreads();
     if (tid < 8) cy.fin_cnt[tid] = 0;
     __syncthreads();
