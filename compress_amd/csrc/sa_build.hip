@@ -733,6 +733,48 @@ __device__ inline int suffix_cmp(const uint8_t *T, uint32_t n, uint32_t pa, uint
     return ca < cb ? -1 : 1;
 }
 
+// does the initial regroup store the ranks through the chunk streams?  (needs the staging area: woff + the peer table)
+template <int DB>
+constexpr bool isa_binned() {
+    return SA_ISA_BINNED && ((size_t)SAM_WAVES * (1 << DB) * 2 + (SA_MTAB ? (size_t)SAM_WAVES * SaLds<DB>::mtab_entries() * 8 : 0)) >= ((size_t)4 << SA_ISA_CH);
+}
+
+// Second half of the binned rank store (see SA_ISA_CH): every chunk's pairs -> LDS -> one run of the rank array.
+template <int DB>
+__device__ inline void isa_flush(const SaLds<DB> &L, const uint32_t *pairs, uint32_t m, int32_t *rk, int tid) {
+    constexpr uint32_t CH = 1u << SA_ISA_CH;
+    constexpr int PER = (int)(CH / SAM_THREADS);
+    uint32_t *stage = reinterpret_cast<uint32_t *>(L.woff);
+    __syncthreads();  // every pair is written
+    for (uint32_t c0 = 0; c0 < m; c0 += CH) {
+        const uint32_t cnt = m - c0 < CH ? m - c0 : CH;
+        uint32_t v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t x = (uint32_t)i * SAM_THREADS + (uint32_t)tid;
+            v[i] = x < cnt ? pairs[c0 + x] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t x = (uint32_t)i * SAM_THREADS + (uint32_t)tid;
+            if (x < cnt) stage[v[i] & (CH - 1u)] = v[i] >> SA_ISA_CH;
+        }
+        __syncthreads();
+        for (uint32_t x = (uint32_t)tid * 4; x < cnt; x += SAM_THREADS * 4) {
+            if (x + 4 <= cnt) {
+                const int2 lo = *reinterpret_cast<const int2 *>(stage + x), hi = *reinterpret_cast<const int2 *>(stage + x + 2);
+                *reinterpret_cast<int4 *>(rk + c0 + x) = make_int4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                for (uint32_t y = x; y < cnt; ++y) rk[c0 + y] = (int)stage[y];
+            }
+        }
+        __syncthreads();
+    }
+    if (SA_MTAB)
+        for (int x = tid; x < SAM_WAVES * SaLds<DB>::mtab_entries(); x += SAM_THREADS) L.mtab[x] = 0;
+    __syncthreads();
+}
+
 // Regroup: `m` sorted records (INITIAL: (initial key, suffix) in key order, one group;
 // otherwise (k1, k2, suffix) sorted by (k1, sequence order)) -> slots, new group starts, bitmaps, next digit counts.
 // Returns the number of suffixes that still share their group.
@@ -742,8 +784,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
     constexpr int NB = 1 << DB;
     constexpr int RS = INITIAL ? SaInit<DB>::SHIFT : 20;  // bits of the suffix index below the key(s)
     // the chunk staging area of the binned rank store: woff and the peer table (both idle here; the table is zeroed again)
-    constexpr size_t STAGE_BYTES = (size_t)SAM_WAVES * NB * 2 + (SA_MTAB ? (size_t)SAM_WAVES * SaLds<DB>::mtab_entries() * 8 : 0);
-    constexpr bool BINNED = INITIAL && SA_ISA_BINNED && STAGE_BYTES >= ((size_t)4 << SA_ISA_CH);
+    constexpr bool BINNED = INITIAL && isa_binned<DB>();
     const int lane = tid & 63, w = tid >> 6;
     int tileK = -1, tileS = -1;
     uint32_t rem = 0;
@@ -840,6 +881,11 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             const bool closed = b < nvalid || nvalid < 64 || nfend[s];
             const int size = b - lane;
             if (valid && (fl[s] & 2) && closed && size >= 2 && size <= SA_FIN_G) fsz[s] = size;
+            if (BINNED) {  // members of a listed group: sa_finish stores their ranks (final, or the group's)
+                const uint64_t heads = __ballot(fsz[s] > 0);
+                const uint64_t lS = bS[s] & lem;  // group starts of this step at or below this lane
+                if (lS && ((heads >> (63 - (int)__builtin_clzll(lS))) & 1)) fl[s] |= 8;
+            }
         }
 #pragma unroll
         for (int s = 0; s < SA_K; ++s) {
@@ -863,7 +909,8 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             }
             if (valid) {
                 sa[slot] = p[s] | ((fS && !sgl) ? (int)0x80000000 : 0);  // top bit: first slot of a shared group
-                if (BINNED) {
+                if (BINNED && (fl[s] & 8)) {
+                } else if (BINNED) {
                     const uint32_t bin = (uint32_t)p[s] >> SA_ISA_CH;
                     const uint32_t at = (uint32_t)atomicAdd(&cy.bin_cur[bin], 1);
                     pairs[(bin << SA_ISA_CH) + at] = ((uint32_t)nr << SA_ISA_CH) | ((uint32_t)p[s] & ((1u << SA_ISA_CH) - 1u));
@@ -889,38 +936,6 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             }
             rem += (uint32_t)__popcll(__ballot(valid && !sgl));
         }
-    }
-    if (BINNED) {
-        constexpr uint32_t CH = 1u << SA_ISA_CH;
-        constexpr int PER = (int)(CH / SAM_THREADS);
-        uint32_t *stage = reinterpret_cast<uint32_t *>(L.woff);
-        __syncthreads();  // every pair is written
-        for (uint32_t c0 = 0; c0 < m; c0 += CH) {
-            const uint32_t cnt = m - c0 < CH ? m - c0 : CH;
-            uint32_t v[PER];
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const uint32_t x = (uint32_t)i * SAM_THREADS + (uint32_t)tid;
-                v[i] = x < cnt ? pairs[c0 + x] : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const uint32_t x = (uint32_t)i * SAM_THREADS + (uint32_t)tid;
-                if (x < cnt) stage[v[i] & (CH - 1u)] = v[i] >> SA_ISA_CH;
-            }
-            __syncthreads();
-            for (uint32_t x = (uint32_t)tid * 4; x < cnt; x += SAM_THREADS * 4) {
-                if (x + 4 <= cnt) {
-                    const int2 lo = *reinterpret_cast<const int2 *>(stage + x), hi = *reinterpret_cast<const int2 *>(stage + x + 2);
-                    *reinterpret_cast<int4 *>(rk + c0 + x) = make_int4(lo.x, lo.y, hi.x, hi.y);
-                } else {
-                    for (uint32_t y = x; y < cnt; ++y) rk[c0 + y] = (int)stage[y];
-                }
-            }
-            __syncthreads();
-        }
-        if (SA_MTAB)
-            for (int x = tid; x < SAM_WAVES * SaLds<DB>::mtab_entries(); x += SAM_THREADS) L.mtab[x] = 0;
     }
     if (lane == 0) cy.wcount[w] = (int)rem;
     __syncthreads();
@@ -1025,7 +1040,8 @@ __device__ inline int finish_group(const uint8_t *T, uint32_t n, const uint32_t 
 // suffixes finished.  d0: symbols the members of a group are known to share.
 template <int DB>
 __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint32_t *fin_list, uint32_t fin_N, int32_t *sa,
-                                     int32_t *rk, const uint8_t *T, uint32_t n, int d0, int tid) {
+                                     int32_t *rk, const uint8_t *T, uint32_t n, int d0, int tid, uint32_t *pairs = nullptr) {
+    // pairs: after the initial regroup (binned rank store) - the ranks of ALL listed members go to the chunk streams
     constexpr int NB = 1 << DB;
     if (SA_FIN_G < 2) return 0;
     __syncthreads();  // the lists, the slots and the counters are complete
@@ -1048,7 +1064,17 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
 #ifdef SA_PROFILE_ROUNDS
             if (ok != 1) atomicAdd(&cy.fin_cnt[ok == 2 ? 6 : 5], z);
 #endif
-            if (ok != 1) continue;
+            if (ok != 1) {
+                if (pairs) {
+#pragma unroll
+                    for (int j = 0; j < z; ++j) {
+                        const uint32_t bin = p[j] >> SA_ISA_CH;
+                        const uint32_t at = (uint32_t)atomicAdd(&cy.bin_cur[bin], 1);
+                        pairs[(bin << SA_ISA_CH) + at] = (slot0 << SA_ISA_CH) | (p[j] & ((1u << SA_ISA_CH) - 1u));
+                    }
+                }
+                continue;
+            }
 #else
 #pragma unroll
             for (int j = 0; j < z; ++j) place[j] = 0;
@@ -1068,7 +1094,13 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
             for (int j = 0; j < z; ++j) {
                 const uint32_t slot = slot0 + (uint32_t)place[j];
                 sa[slot] = (int)p[j];
-                rk[p[j]] = (int)slot;
+                if (pairs) {
+                    const uint32_t bin = p[j] >> SA_ISA_CH;
+                    const uint32_t at = (uint32_t)atomicAdd(&cy.bin_cur[bin], 1);
+                    pairs[(bin << SA_ISA_CH) + at] = (slot << SA_ISA_CH) | (p[j] & ((1u << SA_ISA_CH) - 1u));
+                } else {
+                    rk[p[j]] = (int)slot;
+                }
                 atomicAnd(&L.act[p[j] >> 5], ~(1u << (p[j] & 31)));
             }
             atomicSub(&L.hl[slot0 & (NB - 1)], z);
@@ -1302,7 +1334,9 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     SA_PROF(15)
     uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid, (uint32_t *)(rcur == recA ? recB : recA), N, wk.pairs + sg.off);
     SA_PROF(4)
-    m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), N, sa, rk, T, n, (int)SaInit<DB>::H0, tid);
+    m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), N, sa, rk, T, n, (int)SaInit<DB>::H0, tid,
+                       isa_binned<DB>() ? wk.pairs + sg.off : nullptr);
+    if (isa_binned<DB>()) isa_flush<DB>(L, wk.pairs + sg.off, N, rk, tid);
     SA_PROF(19)
     uint32_t h = SaInit<DB>::H0;  // every group of the initial keys shares at least that many symbols
 #ifdef SA_PROFILE_ROUNDS  // (a device printf costs far more than a round: not in the clocked build)
