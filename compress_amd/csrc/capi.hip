@@ -129,7 +129,7 @@ struct mi355_lzss_batch {
     uint32_t max_blobs = 0;
     uint64_t cap_elems = 0;  // element capacity of the per-position arrays
     // per-position arrays
-    DevBuf text, sortA, sortB, rkA, rkB, flags, rlen, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
+    DevBuf text, sortA, sortB, rkA, rkB, sa_tmp, rlen, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
     DevBuf pmin1, pmax1, pmin2, pmax2, samin1, samin2, dlb;  // per 64 entries
     DevBuf cdir;                                        // per 64 ranks and chunk
     DevBuf tbits;                   // per position
@@ -169,7 +169,7 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
     if (elems > b->cap_elems) {
         const uint64_t e = elems;
 #define R(buf, bytes_per) if ((rc = b->buf.ensure((size_t)(e * (bytes_per)))) != 0) return rc;
-        R(text, 1) R(sortA, 8) R(sortB, 8) R(rlen, 1)  // rkA, rkB, flags: only with the fallback suffix sort (upload)
+        R(text, 1) R(sortA, 8) R(sortB, 8) R(rlen, 1)  // rkA, rkB, sa_tmp: only with texts for the device-wide suffix sort (upload)
         R(sa, 4) R(isa, 4) R(lcp, 2) R(res, 4) R(adv, 1) R(kind, 1) R(exitoff, 1) R(tbits, 2)
 #undef R
         const uint64_t e64 = e / 64 + 1, e256 = e / 256 + 1;
@@ -197,13 +197,11 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
 static SaWork sa_work(mi355_lzss_batch *b) {
     SaWork w;
     w.recA = b->sortA.as<uint64_t>(); w.recB = b->sortB.as<uint64_t>();
-    w.keyA = b->sortA.as<int32_t>(); w.valA = w.keyA + b->cap_elems;
-    w.keyB = b->sortB.as<int32_t>(); w.valB = w.keyB + b->cap_elems;
     w.rkA = b->rkA.as<int32_t>(); w.rkB = b->rkB.as<int32_t>();
-    w.flags = b->flags.as<uint8_t>();
     w.rlen = b->rlen.as<uint8_t>();
     w.sa = b->sa.as<int32_t>(); w.isa = b->isa.as<int32_t>();
     w.pairs = b->res.as<uint32_t>();
+    w.tmp = b->sa_tmp.as<uint8_t>(); w.tmp_bytes = b->sa_tmp.bytes;
     return w;
 }
 static BatchIndex batch_index(mi355_lzss_batch *b) {
@@ -272,7 +270,7 @@ extern "C" int mi355_lzss_batch_create(mi355_lzss_ctx *ctx, uint32_t max_blobs, 
 extern "C" void mi355_lzss_batch_destroy(mi355_lzss_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    DevBuf *bufs[] = {&b->text, &b->sortA, &b->sortB, &b->rkA, &b->rkB, &b->flags, &b->rlen, &b->sa, &b->isa,
+    DevBuf *bufs[] = {&b->text, &b->sortA, &b->sortB, &b->rkA, &b->rkB, &b->sa_tmp, &b->rlen, &b->sa, &b->isa,
                       &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->dlb, &b->cdir, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
                       &b->tbits, &b->segs, &b->src_off, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->flat, &b->out,
                       &b->d_cin, &b->d_cin_off, &b->d_dout, &b->d_dout_off, &b->d_dlen, &b->d_dstatus};
@@ -351,10 +349,10 @@ static int upload_async(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *
     const uint64_t flat_bytes = n_blobs ? in_off[n_blobs] - base : 0;
     if ((rc = batch_reserve(b, std::max<uint32_t>(n_blobs, 1), std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
     if ((rc = b->flat.ensure((size_t)flat_bytes + 16)) != 0) return rc;
-    if (max_n + 1 > SA_BITMAP_MAX_N) {  // the fallback suffix sort keeps ranks and boundary flags in HBM
+    if (max_n + 1 > SA_BITMAP_MAX_N) {  // the device-wide sort of large texts (sa_large.hip) keeps two more arrays in HBM
         const uint64_t e = b->cap_elems;
         if ((rc = b->rkA.ensure((size_t)(e * 4))) != 0 || (rc = b->rkB.ensure((size_t)(e * 4))) != 0 ||
-            (rc = b->flags.ensure((size_t)e)) != 0)
+            (rc = b->sa_tmp.ensure(sa_large_temp_bytes(max_n + 1))) != 0)
             return rc;
     }
     {
@@ -401,7 +399,7 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
     if (b->n_blobs < 8u * (uint32_t)split || b->max_n + 1 > SA_BITMAP_MAX_N || sm != ctx->stream) split = 1;
     if (split == 1) {
         if ((rc = mark(b, ST_SA)) != 0) return rc;
-        launch_sa_build(d_segs, b->n_blobs, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
+        HIP_TRY((hipError_t)launch_sa_build(d_segs, b->h_segs.data(), b->n_blobs, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm));
         if ((rc = mark(b, ST_LCP)) != 0) return rc;
         launch_lcp(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
         if ((rc = mark(b, ST_WINDEX)) != 0) return rc;
@@ -429,7 +427,7 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
         const Seg *sg = d_segs + lo;
         const uint32_t cnt = hi - lo;
         if (k) HIP_TRY(hipStreamWaitEvent(st, ctx->fork_ev, 0));
-        launch_sa_build(sg, cnt, b->max_n, b->text.as<uint8_t>(), sa_work(b), st);
+        HIP_TRY((hipError_t)launch_sa_build(sg, b->h_segs.data() + lo, cnt, b->max_n, b->text.as<uint8_t>(), sa_work(b), st));
         launch_lcp(sg, cnt, b->max_n, batch_index(b), st);
         launch_window_index(sg, cnt, b->max_n, batch_index(b), st);
         launch_match_head(sg, cnt, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), st);
@@ -699,7 +697,7 @@ extern "C" int mi355_lzss_write_noalloc(mi355_lzss_ctx *ctx, const uint8_t *d_in
     b->n_blobs = 1;
     b->max_n = (uint32_t)n;
     const Seg *d_segs = b->segs.as<Seg>();
-    launch_sa_build(d_segs, 1, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
+    HIP_TRY((hipError_t)launch_sa_build(d_segs, nullptr, 1, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm));
     launch_lcp(d_segs, 1, b->max_n, batch_index(b), sm);
     launch_window_index(d_segs, 1, b->max_n, batch_index(b), sm);
     launch_match_head(d_segs, 1, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), sm);
@@ -799,7 +797,7 @@ static int ctx_create(const uint8_t *dict, size_t dict_len, int device, bool dec
     mi355_lzss_batch *b = ctx->scratch;
     const uint64_t off2[2] = {0, aug.size()};
     if ((rc = upload_async(b, aug.data(), off2, 1, nullptr, LZSS_MAX_DICT_SIZE, sm)) != 0) return bail(rc);
-    launch_sa_build(b->segs.as<Seg>(), 1, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm);
+    HIP_TRY((hipError_t)launch_sa_build(b->segs.as<Seg>(), b->h_segs.data(), 1, b->max_n, b->text.as<uint8_t>(), sa_work(b), sm));
     launch_lcp(b->segs.as<Seg>(), 1, b->max_n, batch_index(b), sm);
     if ((rc = ctx->d_text.ensure(stride)) != 0) return bail(rc);
     if ((rc = ctx->d_sa.ensure(stride * 4)) != 0) return bail(rc);

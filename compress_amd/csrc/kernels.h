@@ -6,20 +6,24 @@ namespace lzss {
 
 // ---- sa_build.hip -----------------------------------------------------------------------------
 struct SaWork {       // batch-wide arrays, indexed [seg.off + k], k in [0, n]
-    uint64_t *recA, *recB;               // sort ping-pong of the main kernel (8-byte records, [seg.off + k])
-    int32_t *keyA, *valA, *keyB, *valB;  // the same memory as int32 arrays (fallback kernel: rank key, suffix)
-    int32_t *rkA, *rkB;                  // group ranks, double buffered
-    uint8_t *flags;                      // group-boundary flags
+    uint64_t *recA, *recB;               // sort ping-pong (8-byte records, [seg.off + k])
+    int32_t *rkA, *rkB;                  // large texts only (sa_large.hip): second suffix buffer, group starts
     int32_t *sa, *isa;                   // outputs
     uint8_t *rlen;                       // output: length of the run of equal bytes starting at every position, capped at 255
     uint32_t *pairs;                     // scratch of the main kernel, 4 bytes per suffix ([seg.off + k]; the match results'
                                          // buffer, which nothing uses before the segment is sorted)
+    uint8_t *tmp;                        // scratch of the large-text sort (sa_large.hip), tmp_bytes long; null without large texts
+    size_t tmp_bytes;
 };
-// texts of more than this many suffixes are sorted by the fallback kernel, which uses the sort buffers as whole-batch
-// int32 arrays: no other stage of the batch may run beside it
+// texts of more than this many suffixes are sorted one at a time by the device-wide sort of sa_large.hip
 constexpr uint32_t SA_BITMAP_MAX_N = 1u << 19;
-void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
-                     hipStream_t stream);
+// h_segs: host copy of the segments; needed (and read) only when max_n + 1 > SA_BITMAP_MAX_N - the large texts are then
+// sorted one after the other by launch_sa_large, which synchronises the stream.  Returns 0 or a hipError_t.
+int launch_sa_build(const Seg *d_segs, const Seg *h_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
+                    hipStream_t stream);
+// sa_large.hip: one text of more than SA_BITMAP_MAX_N suffixes on the whole device (rocPRIM radix sort per doubling round)
+size_t sa_large_temp_bytes(uint32_t N);
+int launch_sa_large(const Seg &sg, const uint8_t *d_text, const SaWork &wk, hipStream_t stream);
 
 // ---- match.hip --------------------------------------------------------------------------------
 struct DictView {     // the dictionary index of a ctx (device pointers)

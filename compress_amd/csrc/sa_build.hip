@@ -1,10 +1,9 @@
-// sa_build.hip - suffix array + inverse of every segment of a batch, one workgroup per segment (gfx950):
-// 512 threads in the main kernel (two workgroups per CU), 1024 in the fallback for texts of 512 KiB and more.  Replaces suffixarray.New (lzss/internal/suffixarray/suffixarray.go:32-45, which
-// runs SA-IS, sais.go:128-203) for both the input index (lzss/compress.go:116) and the dictionary
-// index (compress.go:64).  The suffix array of a text is a unique object, so the construction is
-// free to be GPU-shaped: prefix doubling (Manber-Myers bucket induction), every round one stable
-// LSD radix sort of the rank keys, stability from wave-level ballot matching, 16 wave-private
-// histograms in LDS.
+// sa_build.hip - suffix array + inverse of every segment of a batch, one 512-thread workgroup per segment, two
+// workgroups per CU (gfx950); texts of more than 2^19 suffixes go to sa_large.hip.  Replaces suffixarray.New
+// (lzss/internal/suffixarray/suffixarray.go:32-45, which runs SA-IS, sais.go:128-203) for both the input index
+// (lzss/compress.go:116) and the dictionary index (compress.go:64).  The suffix array of a text is a unique object, so
+// the construction is free to be GPU-shaped: prefix doubling (Manber-Myers bucket induction), every round one stable
+// LSD radix sort of the rank keys, stability from wave-level peer matching, wave-private histograms in LDS.
 //
 // N-world: the text gets an explicit smallest sentinel at index n, N = n + 1 suffixes, SA[0] == n.
 //
@@ -21,10 +20,9 @@
 
 namespace lzss {
 
-constexpr int SA_THREADS = 1024;
+constexpr int SA_THREADS = 1024;         // window_index_kernel (the suffix sort proper: SAM_THREADS below)
 constexpr int SA_WAVES = SA_THREADS / 64;
-constexpr int SA_MAXDB = 9;              // radix digit width (bits) at most
-constexpr int SA_BINS = 1 << SA_MAXDB;
+constexpr int SA_BINS = 512;             // chunks of 2^14 positions a text of MaxInputSize has at most: 256
 
 struct SaShared {
     int32_t hist[SA_WAVES][SA_BINS];
@@ -35,19 +33,7 @@ struct SaShared {
 
 __device__ inline uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
-// lanes of `amask` holding the same digit as this lane
-__device__ inline uint64_t match_digit(int d, uint64_t amask) {
-    uint64_t peers = amask;
-#pragma unroll
-    for (int bit = 0; bit < SA_MAXDB; ++bit) {
-        const bool b = (d >> bit) & 1;
-        const uint64_t bal = __ballot(b);
-        peers &= b ? bal : ~bal;
-    }
-    return peers;
-}
-
-// the same with a runtime number of digit bits (wave-uniform)
+// lanes of `amask` holding the same digit as this lane; the digit has `nbits` bits (wave-uniform)
 __device__ inline uint64_t match_digit_n(int d, uint64_t amask, int nbits) {
     uint64_t peers = amask;
     for (int bit = 0; bit < nbits; ++bit) {
@@ -66,263 +52,10 @@ __device__ inline int wave_incl_add(int v, int lane) {
     }
     return v;
 }
-__device__ inline int wave_incl_max(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (lane >= o) v = v > t ? v : t;
-    }
-    return v;
-}
 
 __device__ inline void hist_clear(SaShared &sh, int tid) {
     for (int x = tid; x < SA_WAVES * SA_BINS; x += SA_THREADS) (&sh.hist[0][0])[x] = 0;
 }
-
-// one wave adds the digits of its 64 keys to its private histogram row
-__device__ inline void hist_add(int32_t *hrow, int d, bool active, int lane) {
-    const uint64_t amask = __ballot(active);
-    const uint64_t peers = match_digit(d, amask);
-    const int cnt = __popcll(peers);
-    const int rank = __popcll(peers & lanemask_lt(lane));
-    if (active && rank == cnt - 1) hrow[d] += cnt;
-}
-
-// hist[w][d] (counts) -> first output index of wave w's keys with digit d (digit-major, wave-minor)
-__device__ inline void hist_scan(SaShared &sh, int tid, int nbins) {
-    __syncthreads();
-    if (tid < nbins) {
-        int s = 0;
-        for (int w = 0; w < SA_WAVES; ++w) {
-            int t = sh.hist[w][tid];
-            sh.hist[w][tid] = s;
-            s += t;
-        }
-        sh.colsum[tid] = s;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        int carry = 0;
-        for (int base = 0; base < nbins; base += 64) {
-            int v = sh.colsum[base + tid];
-            int inc = wave_incl_add(v, tid);
-            sh.colsum[base + tid] = carry + inc - v;
-            carry += __shfl(inc, 63);
-        }
-    }
-    __syncthreads();
-    if (tid < nbins) {
-        int base = sh.colsum[tid];
-        for (int w = 0; w < SA_WAVES; ++w) sh.hist[w][tid] += base;
-    }
-    __syncthreads();
-}
-
-// stable scatter of this wave's chunk [cbeg, cend) by digit (key >> shift) & mask
-__device__ inline void scatter_chunk(SaShared &sh, const int32_t *kin, const int32_t *vin, int32_t *kout,
-                                     int32_t *vout, uint32_t cbeg, uint32_t cend, int shift, int mask, int w,
-                                     int lane) {
-    int32_t *hrow = sh.hist[w];
-    for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool active = j < cend;
-        int key = 0, val = 0;
-        if (active) {
-            key = kin[j];
-            val = vin[j];
-        }
-        const int d = (key >> shift) & mask;
-        const uint64_t amask = __ballot(active);
-        const uint64_t peers = match_digit(d, amask);
-        const int cnt = __popcll(peers);
-        const int rank = __popcll(peers & lanemask_lt(lane));
-        const int base = hrow[d];
-        if (active) {
-            kout[base + rank] = key;
-            vout[base + rank] = val;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (active && rank == cnt - 1) hrow[d] = base + cnt;
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-__device__ inline void count_chunk(SaShared &sh, const int32_t *kin, uint32_t cbeg, uint32_t cend, int shift,
-                                   int mask, int w, int lane) {
-    int32_t *hrow = sh.hist[w];
-    for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool active = j < cend;
-        const int key = active ? kin[j] : 0;
-        hist_add(hrow, (key >> shift) & mask, active, lane);
-    }
-}
-
-// Fallback for texts whose activity bitmap does not fit LDS: every round sorts ALL suffixes.
-__global__ __launch_bounds__(SA_THREADS) void sa_build_full_kernel(const Seg *segs, const uint8_t *text, SaWork wk) {
-    __shared__ SaShared sh;
-    const Seg sg = segs[blockIdx.x];
-    const uint8_t *T = text + sg.off;
-    const uint32_t n = sg.n;
-    const uint32_t N = n + 1;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-
-    int32_t *keyA = wk.keyA + sg.off, *valA = wk.valA + sg.off;
-    int32_t *keyB = wk.keyB + sg.off, *valB = wk.valB + sg.off;
-    int32_t *rk = wk.rkA + sg.off, *rknew = wk.rkB + sg.off;
-    uint8_t *flags = wk.flags + sg.off;
-    int32_t *sa_out = wk.sa + sg.off, *isa_out = wk.isa + sg.off;
-
-    if (N == 1) {
-        if (tid == 0) {
-            sa_out[0] = 0;
-            isa_out[0] = 0;
-        }
-        return;
-    }
-
-    const uint32_t C = (((N + SA_WAVES - 1) / SA_WAVES) + 63u) & ~63u;  // per-wave chunk of the sequence
-    const uint32_t cbeg = min((uint32_t)w * C, N), cend = min(cbeg + C, N);
-
-    const int KB = 32 - __clz((int)(N - 1));  // bits of the largest rank key
-    const int P = (KB + SA_MAXDB - 1) / SA_MAXDB;
-    const int DB = (KB + P - 1) / P;
-
-    // ---- initial order: by first symbol (0 = sentinel, byte + 1 otherwise), one 9-bit pass
-    hist_clear(sh, tid);
-    __syncthreads();
-    for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool active = j < cend;
-        int key = 0;
-        if (active) {
-            key = j < n ? (int)T[j] + 1 : 0;
-            keyA[j] = key;
-            valA[j] = (int)j;
-        }
-        hist_add(sh.hist[w], key, active, lane);
-    }
-    hist_scan(sh, tid, SA_BINS);
-    scatter_chunk(sh, keyA, valA, keyB, valB, cbeg, cend, 0, SA_BINS - 1, w, lane);
-    __syncthreads();
-    int32_t *kcur = keyB, *vcur = valB;  // sorted keys / current suffix order
-
-    uint32_t h = 0;  // sorted depth; 0 = "rank by the key alone"
-    for (;;) {
-        // ---- ranks of the new order: RK'[p] = first index of the group of equal (key, second key)
-        {
-            int lastf = -1, cntf = 0;
-            int c1 = 0, c2 = 0;
-            for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                const bool active = j < cend;
-                int p = 0, k1 = -2, k2 = -1;
-                if (active) {
-                    p = vcur[j];
-                    k1 = kcur[j];
-                    if (h != 0 && (uint32_t)p + h < N) k2 = rk[(uint32_t)p + h];
-                }
-                int q1 = __shfl_up(k1, 1), q2 = __shfl_up(k2, 1);
-                if (lane == 0) {
-                    if (j0 == cbeg) {
-                        if (j > 0) {
-                            const int pp = vcur[j - 1];
-                            q1 = kcur[j - 1];
-                            q2 = (h != 0 && (uint32_t)pp + h < N) ? rk[(uint32_t)pp + h] : -1;
-                        } else {
-                            q1 = -3;
-                        }
-                    } else {
-                        q1 = c1;
-                        q2 = c2;
-                    }
-                }
-                const bool flag = active && (k1 != q1 || k2 != q2);
-                c1 = __shfl(k1, 63);
-                c2 = __shfl(k2, 63);
-                if (active) flags[j] = flag ? 1 : 0;
-                const uint64_t fb = __ballot(flag);
-                cntf += __popcll(fb);
-                if (fb) lastf = (int)j0 + 63 - __clzll(fb);
-            }
-            if (lane == 0) {
-                sh.wlast[w] = lastf;
-                sh.wcount[w] = cntf;
-            }
-            __syncthreads();
-            int carry = -1, total = 0;
-            for (int ww = 0; ww < SA_WAVES; ++ww) {
-                if (ww < w) carry = max(carry, sh.wlast[ww]);
-                total += sh.wcount[ww];
-            }
-            for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                const bool active = j < cend;
-                int g = -1, p = 0;
-                if (active) {
-                    p = vcur[j];
-                    if (flags[j]) g = (int)j;
-                }
-                g = wave_incl_max(g, lane);
-                g = max(g, carry);
-                carry = __shfl(g, 63);
-                if (active) rknew[p] = g;
-            }
-            __syncthreads();
-            int32_t *t = rk;
-            rk = rknew;
-            rknew = t;
-            if ((uint32_t)total == N || h >= N) break;  // every suffix alone in its group: done (h >= N cannot happen)
-        }
-        h = (h == 0) ? 1 : h * 2;
-
-        // ---- sequence of this round into (keyA, valA), fused with the count of digit 0
-        hist_clear(sh, tid);
-        __syncthreads();
-        const int mask = (1 << DB) - 1;
-        for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-            const uint32_t j = j0 + lane;
-            const bool active = j < cend;
-            int key = 0;
-            if (active) {
-                const uint32_t s = (uint32_t)vcur[j];
-                const uint32_t p = s >= h ? s - h : N - h + s;
-                key = rk[p];
-                keyA[j] = key;
-                valA[j] = (int)p;
-            }
-            hist_add(sh.hist[w], key & mask, active, lane);
-        }
-        // ---- P stable passes, least significant digit first
-        int32_t *kin = keyA, *vin = valA, *kout = keyB, *vout = valB;
-        for (int pass = 0; pass < P; ++pass) {
-            if (pass > 0) {
-                hist_clear(sh, tid);
-                __syncthreads();
-                count_chunk(sh, kin, cbeg, cend, pass * DB, mask, w, lane);
-            }
-            hist_scan(sh, tid, 1 << DB);
-            scatter_chunk(sh, kin, vin, kout, vout, cbeg, cend, pass * DB, mask, w, lane);
-            __syncthreads();
-            int32_t *t;
-            t = kin; kin = kout; kout = t;
-            t = vin; vin = vout; vout = t;
-        }
-        kcur = kin;
-        vcur = vin;
-    }
-
-    // ---- final order and ranks (rk holds the exact rank of every suffix now)
-    for (uint32_t j0 = cbeg; j0 < cend; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        if (j < cend) {
-            const int p = vcur[j];
-            sa_out[j] = p;
-            isa_out[p] = (int)j;
-        }
-    }
-}
-
 
 // ---- main kernel --------------------------------------------------------------------------------------
 // Rounds touch only the suffixes that still share their group, and every sort pass is a WORKGROUP-wide
@@ -1640,9 +1373,8 @@ void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, con
     hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.samin1, ix.samin2, 1, 1);  // samin1: lcp_kernel
 }
 
-void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
-                     hipStream_t stream) {
-    if (n_segs == 0) return;
+static void launch_sa_small(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
+                            hipStream_t stream) {
 #ifdef LZSS_DEBUG_KNOBS  // timing experiments only (scripts/build_variants.sh); the shipped library ignores the environment
     static const int max_rounds = getenv("MI355_LZSS_SA_ROUNDS") ? atoi(getenv("MI355_LZSS_SA_ROUNDS")) : 1000;
 #else
@@ -1665,13 +1397,38 @@ void launch_sa_build(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const u
     if (N <= (1u << 18)) {
         hipLaunchKernelGGL(sa_build_kernel<9>, dim3(n_segs), dim3(SAM_THREADS), SaLds<9>::bytes(sa_bitmap_words<9>(N)), stream,
                            d_segs, d_text, wk, max_rounds);
-    } else if (N <= SA_BITMAP_MAX_N) {
+    } else {
         hipLaunchKernelGGL(sa_build_kernel<10>, dim3(n_segs), dim3(SAM_THREADS), SaLds<10>::bytes(sa_bitmap_words<10>(N)), stream,
                            d_segs, d_text, wk, max_rounds);
-    } else {
-        hipLaunchKernelGGL(sa_build_full_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, d_text, wk);
-        hipLaunchKernelGGL(rlen_kernel, dim3((N + 255) / 256, n_segs), dim3(256), 0, stream, d_segs, d_text, wk.rlen);
     }
+}
+
+int launch_sa_build(const Seg *d_segs, const Seg *h_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
+                    hipStream_t stream) {
+    if (n_segs == 0) return 0;
+    if (max_n + 1 <= SA_BITMAP_MAX_N) {
+        launch_sa_small(d_segs, n_segs, max_n, d_text, wk, stream);
+        return 0;
+    }
+    // a batch with large texts: runs of smaller ones go to the one-workgroup kernels, every large one to the device-wide sort
+    if (!h_segs || !wk.tmp) return (int)hipErrorInvalidValue;
+    for (uint32_t k = 0; k < n_segs;) {
+        if (h_segs[k].n + 1 > SA_BITMAP_MAX_N) {
+            const int rc = launch_sa_large(h_segs[k], d_text, wk, stream);
+            if (rc != 0) return rc;
+            hipLaunchKernelGGL(rlen_kernel, dim3((h_segs[k].n + 256) / 256, 1), dim3(256), 0, stream, d_segs + k, d_text, wk.rlen);
+            ++k;
+            continue;
+        }
+        uint32_t e = k, mx = 0;
+        while (e < n_segs && h_segs[e].n + 1 <= SA_BITMAP_MAX_N) {
+            mx = h_segs[e].n > mx ? h_segs[e].n : mx;
+            ++e;
+        }
+        launch_sa_small(d_segs + k, e - k, mx, d_text, wk, stream);
+        k = e;
+    }
+    return 0;
 }
 
 }  // namespace lzss

@@ -113,8 +113,9 @@ def test_small_groups_and_lcp_variants_match_oracle(amd, dict_naive):
 
 def test_text_sizes_across_the_suffix_sort_variants(amd, dict_naive):
     """the suffix sort has three code paths by text size: 9-bit digits (N <= 2^18), 10-bit digits (N <= 2^19) and the
-    every-round-sorts-everything fallback above; a batch picks one by its LARGEST text, so each is exercised with a
-    ragged batch (small texts ride along) and checked on index and bytes"""
+    device-wide sort of sa_large.hip above; the one-workgroup kernels are picked by a batch's LARGEST text and the
+    large texts go one by one, so each path is exercised with a ragged batch (small texts ride along) and checked on
+    index and bytes"""
     big = b"".join(amd.synth.blob(k) for k in range(20, 25))  # 640 KiB of calldata-like bytes
     for n_big in (262143, 262144, 280000, 524287, 524288):
         cases = [big[:n_big], b"", b"x", amd.synth.blob(3)[:5000], bytes(70000)]
@@ -129,6 +130,27 @@ def test_text_sizes_across_the_suffix_sort_variants(amd, dict_naive):
             assert sa[0] == len(d)
             assert np.array_equal(sa[1:], O.suffix_array(d)), f"n_big={n_big} case {k}"
             assert got[k] == oc.compress(d), f"n_big={n_big} case {k}"
+
+
+def test_large_periodic_texts(amd):
+    """sa_large.hip on texts whose suffixes share megabytes (many doubling rounds), mixed with small texts in one batch;
+    the index against the oracle's suffix array, the bytes through the GPU round trip (the oracle's match search takes
+    minutes on these)"""
+    rng = np.random.default_rng(5)
+    blk = bytes(rng.integers(0, 256, 1000, dtype=np.uint8))
+    cases = [(b"abc" * 250000)[:700001], b"tiny", bytes(600000), (blk * 700)[:650000], amd.synth.blob(7),
+             bytes(rng.integers(0, 2, 530000, dtype=np.uint8))]
+    ctx = amd.batch.new_ctx(b"")
+    b = amd.batch.Batch(ctx, len(cases), sum(map(len, cases)))
+    b.upload(cases)
+    b.compress()
+    got = b.download()
+    for k, d in enumerate(cases):
+        sa, isa, lcp = b.index(k)
+        assert sa[0] == len(d)
+        assert np.array_equal(sa[1:], O.suffix_array(d)), f"case {k}"
+        assert np.array_equal(isa[sa], np.arange(len(d) + 1))
+        assert amd.Decompress(got[k], b"") == d, f"case {k}"
 
 
 def test_overlapped_sub_batches_give_the_same_bytes(amd, dict_naive):
