@@ -106,8 +106,8 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs,
     const uint32_t rw = reinterpret_cast<const uint32_t *>(rlen + gbase)[lane];
     const uint4 rr = reinterpret_cast<const uint4 *>(res + gbase)[lane];
     // what the lane's last positions see in the next lane / the next tile, and its first one in the previous
-    uint32_t tn = (uint32_t)__shfl_down((int)tw, 1), tp = (uint32_t)__shfl_up((int)tw, 1) >> 24;
-    uint32_t rn0 = (uint32_t)__shfl_down((int)rr.x, 1), rn1 = (uint32_t)__shfl_down((int)rr.y, 1);
+    uint32_t tn = (uint32_t)lane_above((int)tw, 0), tp = (uint32_t)lane_below((int)tw, 0) >> 24;
+    uint32_t rn0 = (uint32_t)lane_above((int)rr.x, 0), rn1 = (uint32_t)lane_above((int)rr.y, 0);
     if (lane == 63) {
         tn = tend < n ? (uint32_t)T[tend] : 0u;
         rn0 = tend < n ? R[tend] : 0u;
@@ -418,14 +418,9 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         nb[j] = xs[j] < TILE ? kind_bits(s_kind[xs[j]]) : 0u;
-        uint32_t inc = nb[j];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(inc, o);
-            if (lane >= o) inc += v;
-        }
+        const uint32_t inc = (uint32_t)wave_incl_add((int)nb[j], lane);
         off[j] = lead + total + inc - nb[j];
-        total += __shfl(inc, 63);
+        total += (uint32_t)lane_value((int)inc, 63);
     }
     const SegIndex S = seg_index(ix, sg);
 #pragma unroll

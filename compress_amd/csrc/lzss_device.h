@@ -87,6 +87,53 @@ struct IndexView {
 __device__ inline uint32_t xcd_block(uint32_t b, uint32_t nblk) { return (b & 7u) * (nblk >> 3) + (b >> 3); }
 inline uint32_t xcd_grid(uint64_t blocks) { return (uint32_t)((blocks + 7) / 8 * 8); }
 
+// ---- wave-level data movement without the LDS crossbar ------------------------------------------------
+// The value of lane `l` (wave-uniform) in every lane: one v_readlane instead of a trip through the LDS crossbar
+// (__shfl compiles to ds_bpermute_b32 and a wait for it).
+__device__ inline int lane_value(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ inline uint64_t lane_value(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+// the value of the lane below (lane 0 keeps `first`): a DPP move, wave_shr:1
+__device__ inline int lane_below(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false); }
+__device__ inline uint64_t lane_below(uint64_t v, uint64_t first) {
+    const uint32_t lo = (uint32_t)lane_below((int)(uint32_t)v, (int)(uint32_t)first);
+    const uint32_t hi = (uint32_t)lane_below((int)(uint32_t)(v >> 32), (int)(uint32_t)(first >> 32));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+// the value of the lane above (lane 63 keeps `last`): wave_shl:1
+__device__ inline int lane_above(int v, int last) { return __builtin_amdgcn_update_dpp(last, v, 0x130, 0xF, 0xF, false); }
+
+// inclusive prefix sum over the wave by DPP moves (no LDS crossbar): four row shifts scan each row of 16 lanes, two row
+// broadcasts carry the row totals on (rows 1 and 3 take lane 15 of the row below them, then rows 2 and 3 take lane 31)
+__device__ inline int wave_incl_add(int v, int lane) {
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// inclusive prefix minimum over the wave, the same way (a lane without a source keeps its own value)
+__device__ inline int wave_incl_min_dpp(int v) {
+#define LZSS_DPP_MIN(ctrl, rows)                                                        \
+    {                                                                                  \
+        const int t_ = __builtin_amdgcn_update_dpp(v, v, ctrl, rows, 0xF, false);      \
+        v = t_ < v ? t_ : v;                                                           \
+    }
+    LZSS_DPP_MIN(0x111, 0xF) LZSS_DPP_MIN(0x112, 0xF) LZSS_DPP_MIN(0x114, 0xF) LZSS_DPP_MIN(0x118, 0xF)
+    LZSS_DPP_MIN(0x142, 0xA) LZSS_DPP_MIN(0x143, 0xC)
+#undef LZSS_DPP_MIN
+    return v;
+}
+// minimum over the wave, in every lane
+__device__ inline int wave_min(int v) { return __builtin_amdgcn_readlane(wave_incl_min_dpp(v), 63); }
+
 // 8 bytes at any byte address (amdhsa runs with unaligned access enabled)
 __device__ inline uint64_t ld8(const uint8_t *p) {
     uint64_t v;

@@ -88,9 +88,9 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint3
         rb = run_at(sak, wb);
     }
     // the upper suffix of the pair is the neighbour lane's; the first lane of a wave fetches it
-    int a = __shfl_up(sak, 1);
-    uint64_t wa = __shfl_up(wb, 1);
-    int ra = __shfl_up(rb, 1);
+    int a = lane_below(sak, 0);
+    uint64_t wa = lane_below(wb, 0ull);
+    int ra = lane_below(rb, 0);
     if ((threadIdx.x & 63) == 0 && k > 0 && k < N) {
         a = SA[k - 1];
         wa = ld8(T + a);
@@ -109,15 +109,8 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint3
             for (uint32_t e = 0; e < 4; ++e) ix.lcp[sg.off + N + e] = 0;
     }
     // minimum of LCP and of SA over the 64 ranks of this wave
-    uint32_t m = l;
-    int ms = sak;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
-        const int u = __shfl_xor(ms, o);
-        m = t < m ? t : m;
-        ms = u < ms ? u : ms;
-    }
+    const uint32_t m = (uint32_t)wave_min((int)l);  // (l <= 0xFFFF: the signed minimum is the unsigned one)
+    const int ms = wave_min(sak);
     if ((threadIdx.x & 63) == 0) {
         ix.bmin1[sg.off / 64 + (k >> 6)] = (uint16_t)m;
         ix.samin1[sg.off / 64 + (k >> 6)] = ms;
@@ -166,9 +159,9 @@ __global__ __launch_bounds__(LCPL_THREADS) void lcp_lds_kernel(const Seg *segs, 
             wb = ld8s((uint32_t)sak);
             rb = run_at(sak, wb);
         }
-        int a = __shfl_up(sak, 1);
-        uint64_t wa = __shfl_up(wb, 1);
-        int ra = __shfl_up(rb, 1);
+        int a = lane_below(sak, 0);
+        uint64_t wa = lane_below(wb, 0ull);
+        int ra = lane_below(rb, 0);
         if (lane == 0 && k > 0 && k < N) {
             a = SA[k - 1];
             wa = ld8s((uint32_t)a);
@@ -207,15 +200,8 @@ __global__ __launch_bounds__(LCPL_THREADS) void lcp_lds_kernel(const Seg *segs, 
             if (k == N - 1)
                 for (uint32_t e = 0; e < 4; ++e) ix.lcp[sg.off + N + e] = 0;
         }
-        uint32_t m = l;
-        int ms = sak;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
-            const int u = __shfl_xor(ms, o);
-            m = t < m ? t : m;
-            ms = u < ms ? u : ms;
-        }
+        const uint32_t m = (uint32_t)wave_min((int)l);  // (l <= 0xFFFF: the signed minimum is the unsigned one)
+        const int ms = wave_min(sak);
         if (lane == 0 && k < N) {  // (a block past the last rank would land in the next segment's summaries)
             ix.bmin1[sg.off / 64 + (k >> 6)] = (uint16_t)m;
             ix.samin1[sg.off / 64 + (k >> 6)] = ms;
@@ -616,12 +602,8 @@ __device__ inline uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) {
 }
 
 __device__ inline int wave_incl_min(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v = t < v ? t : v;
-    }
-    return v;
+    (void)lane;
+    return wave_incl_min_dpp(v);
 }
 
 // One lane per rank.  The walks to the nearest in-window neighbours are short for most ranks and very long
@@ -742,17 +724,17 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
         MP(1)
         for (uint64_t hm = (ablate & 16) ? 0ull : __ballot(!done); hm; hm &= hm - 1) {  // the wave finishes lane t's walk
             const int t = (int)__builtin_ctzll(hm);
-            const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cminD = __shfl(minD, t);
-            int cmin = __shfl(minS, t);  // the lcp below which the walk ends; raised by a useful long-window hit (see above)
-            int cm = __shfl(m, t);
-            bool cfL = __shfl((int)(qupL != NONE_UP), t) != 0;
+            const int ci = lane_value(i, t), cws = lane_value(wsS, t), cwl = lane_value(wsL, t), cminD = lane_value(minD, t);
+            int cmin = lane_value(minS, t);  // the lcp below which the walk ends; raised by a useful long-window hit (see above)
+            int cm = lane_value(m, t);
+            bool cfL = lane_value((int)(qupL != NONE_UP), t) != 0;
             {
-                const int lv = __shfl((int)(qupL & 511u), t);
+                const int lv = lane_value((int)(qupL & 511u), t);
                 if (cfL && lv >= cminD && lv > cmin) cmin = lv;
             }
             uint32_t rL = NONE_UP, rS = NONE_UP;
             DS(11, 1)
-            for (int base = __shfl(k, t); base < N; base += 64) {
+            for (int base = lane_value(k, t); base < N; base += 64) {
                 DS(12, 1)
                 const int kk = base + lane;
                 const bool valid = kk < N;
@@ -764,7 +746,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
                     const uint64_t bL = __ballot(pm >= cmin && p < ci && p >= cwl);
                     if (bL) {
                         const int t2 = (int)__builtin_ctzll(bL);
-                        const int lv = __shfl(pm, t2);
+                        const int lv = lane_value(pm, t2);
                         rL = ((uint32_t)(base + t2) << 9) | (uint32_t)lv;
                         cfL = true;
                         if (lv >= cminD && lv > cmin) cmin = lv;
@@ -775,11 +757,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
                 const uint64_t bDead = __ballot(!alive);
                 if (bS) {
                     const int t2 = (int)__builtin_ctzll(bS);
-                    rS = ((uint32_t)(base + t2) << 9) | (uint32_t)__shfl(pm, t2);
+                    rS = ((uint32_t)(base + t2) << 9) | (uint32_t)lane_value(pm, t2);
                     break;
                 }
                 if (bDead) break;
-                cm = __shfl(pm, 63);
+                cm = lane_value(pm, 63);
             }
             if (lane == t) {
                 if (rL != NONE_UP) qupL = rL;
@@ -842,17 +824,17 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
         MP(3)
         for (uint64_t hm = (ablate & 16) ? 0ull : __ballot(!done); hm; hm &= hm - 1) {
             const int t = (int)__builtin_ctzll(hm);
-            const int ci = __shfl(i, t), cws = __shfl(wsS, t), cwl = __shfl(wsL, t), cminD = __shfl(minD, t);
-            int cmin = __shfl(floor0, t);
-            int cm = __shfl(m, t);
-            bool cfL = __shfl((int)(qdnL != NONE_DN), t) != 0;
+            const int ci = lane_value(i, t), cws = lane_value(wsS, t), cwl = lane_value(wsL, t), cminD = lane_value(minD, t);
+            int cmin = lane_value(floor0, t);
+            int cm = lane_value(m, t);
+            bool cfL = lane_value((int)(qdnL != NONE_DN), t) != 0;
             {
-                const int lv = __shfl((int)(qdnL & 511u), t);
+                const int lv = lane_value((int)(qdnL & 511u), t);
                 if (cfL && lv >= cminD && lv > cmin) cmin = lv;
             }
             uint32_t rL = NONE_DN, rS = NONE_DN;
             DS(13, 1)
-            for (int base = __shfl(k, t); base >= 1; base -= 64) {
+            for (int base = lane_value(k, t); base >= 1; base -= 64) {
                 DS(14, 1)
                 const int kk = base - lane;
                 const bool valid = kk >= 1;
@@ -864,7 +846,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
                     const uint64_t bL = __ballot(pm >= cmin && p < ci && p >= cwl);
                     if (bL) {
                         const int t2 = (int)__builtin_ctzll(bL);
-                        const int lv = __shfl(pm, t2);
+                        const int lv = lane_value(pm, t2);
                         rL = ((uint32_t)(base - t2) << 9) | (uint32_t)lv;
                         cfL = true;
                         if (lv >= cminD && lv > cmin) cmin = lv;
@@ -875,11 +857,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, u
                 const uint64_t bDead = __ballot(!alive);
                 if (bS) {
                     const int t2 = (int)__builtin_ctzll(bS);
-                    rS = ((uint32_t)(base - t2) << 9) | (uint32_t)__shfl(pm, t2);
+                    rS = ((uint32_t)(base - t2) << 9) | (uint32_t)lane_value(pm, t2);
                     break;
                 }
                 if (bDead) break;
-                cm = __shfl(pm, 63);
+                cm = lane_value(pm, 63);
             }
             if (lane == t) {
                 if (rL != NONE_DN) qdnL = rL;

@@ -44,14 +44,6 @@ __device__ inline uint64_t match_digit_n(int d, uint64_t amask, int nbits) {
     return peers;
 }
 
-__device__ inline int wave_incl_add(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
 
 __device__ inline void hist_clear(SaShared &sh, int tid) {
     for (int x = tid; x < SA_WAVES * SA_BINS; x += SA_THREADS) (&sh.hist[0][0])[x] = 0;
@@ -255,7 +247,7 @@ __device__ inline uint64_t wave_peers(uint64_t *mrow, int d, bool valid, int lan
     for (int r = 0; r < SA_PEER_ROUNDS; ++r) {
         const uint64_t rem = __ballot(todo);
         if (rem) {
-            const int dl = __shfl(d, (int)__builtin_ctzll(rem));
+            const int dl = lane_value(d, (int)__builtin_ctzll(rem));
             const bool eq = todo && d == dl;
             const uint64_t e = __ballot(eq);
             if (eq) {
@@ -347,7 +339,7 @@ __device__ inline void digit_count(int32_t *hist, int d, bool valid, int lane) {
         const uint64_t rem = __ballot(todo);
         if (rem) {
             const int first = (int)__builtin_ctzll(rem);
-            const int dl = __shfl(d, first);
+            const int dl = lane_value(d, first);
             const bool eq = todo && d == dl;
             const uint64_t em = __ballot(eq);
             if (lane == first) atomicAdd(&hist[dl], __popcll(em));
@@ -365,7 +357,7 @@ __device__ inline void bins_scan(const int32_t *src, int32_t *base, int nb, int 
             const int v = src[b0 + tid];
             const int inc = wave_incl_add(v, tid);
             base[b0 + tid] = carry + inc - v;
-            carry += __shfl(inc, 63);
+            carry += lane_value(inc, 63);
         }
     }
     __syncthreads();
@@ -548,9 +540,8 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
 #pragma unroll
         for (int s = 0; s < SA_K; ++s) {
             const uint32_t u = wb + s * 64 + lane;
-            uint64_t q = __shfl_up(key[s], 1);
-            const uint64_t q63 = __shfl(key[s > 0 ? s - 1 : 0], 63);  // executed by all lanes
-            if (lane == 0) q = (s == 0) ? pkey : q63;
+            const uint64_t q63 = lane_value(key[s > 0 ? s - 1 : 0], 63);
+            const uint64_t q = lane_below(key[s], (s == 0) ? pkey : q63);
             const bool valid = u < m;
             const bool first = (u == 0);
             const bool fS = valid && (first || key[s] != q);
@@ -573,7 +564,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             else if (s + 1 < SA_K) nf = bS[s + 1 < SA_K ? s + 1 : s] & 1;
             else nf = (un < m) ? (nkey != key[s]) : true;
             if (u + 1 >= m) nf = true;
-            nfend[s] = __shfl((int)nf, 63) != 0;  // the entry behind this step starts a run (or there is none)
+            nfend[s] = lane_value((int)nf, 63) != 0;  // the entry behind this step starts a run (or there is none)
             if ((fl[s] & 2) && nf) fl[s] |= 4;
             // index of the last marked entry at or before this one: from the ballots, no scans
             const int u0 = (int)(wb + s * 64);
@@ -636,7 +627,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
                     if (em == 0) continue;
                     int base = 0;
                     if (lane == (int)__builtin_ctzll(em)) base = atomicAdd(&cy.fin_cnt[z - 2], __popcll(em));
-                    base = __shfl(base, (int)__builtin_ctzll(em));
+                    base = lane_value(base, (int)__builtin_ctzll(em));
                     if (fsz[s] == z) fin_list[fin_list_base(z, fin_N) + (uint32_t)base + (uint32_t)__popcll(em & lanemask_lt(lane))] = (uint32_t)slot;
                 }
             }
