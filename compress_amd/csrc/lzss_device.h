@@ -131,8 +131,19 @@ __device__ inline int wave_incl_min_dpp(int v) {
 #undef LZSS_DPP_MIN
     return v;
 }
-// minimum over the wave, in every lane
+// minimum / maximum over the wave, in every lane
 __device__ inline int wave_min(int v) { return __builtin_amdgcn_readlane(wave_incl_min_dpp(v), 63); }
+__device__ inline int wave_max(int v) {
+#define LZSS_DPP_MAX(ctrl, rows)                                                        \
+    {                                                                                  \
+        const int t_ = __builtin_amdgcn_update_dpp(v, v, ctrl, rows, 0xF, false);      \
+        v = t_ > v ? t_ : v;                                                           \
+    }
+    LZSS_DPP_MAX(0x111, 0xF) LZSS_DPP_MAX(0x112, 0xF) LZSS_DPP_MAX(0x114, 0xF) LZSS_DPP_MAX(0x118, 0xF)
+    LZSS_DPP_MAX(0x142, 0xA) LZSS_DPP_MAX(0x143, 0xC)
+#undef LZSS_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 // 8 bytes at any byte address (amdhsa runs with unaligned access enabled)
 __device__ inline uint64_t ld8(const uint8_t *p) {

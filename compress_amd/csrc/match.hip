@@ -217,11 +217,7 @@ __global__ __launch_bounds__(64) void bmin2_kernel(const Seg *segs, BatchIndex i
     if (c * 64 >= nb1) return;
     const uint32_t b = c * 64 + threadIdx.x;
     uint32_t m = b < nb1 ? (uint32_t)ix.bmin1[sg.off / 64 + b] : 0xFFFFu;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t t = (uint32_t)__shfl_xor((int)m, o);
-        m = t < m ? t : m;
-    }
+    m = (uint32_t)wave_min((int)m);
     if (threadIdx.x == 0) ix.bmin2[sg.off / 64 + c] = (uint16_t)m;
 }
 

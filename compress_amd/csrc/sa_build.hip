@@ -1301,12 +1301,8 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
         const uint32_t j = b * 64 + lane;
         int lo = INT_MAX, hi = INT_MIN;
         if (j < n) lo = hi = E[j] & emask;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int x = __shfl_xor(lo, o), y = __shfl_xor(hi, o);
-            lo = x < lo ? x : lo;
-            hi = y > hi ? y : hi;
-        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
         if (lane == 0) {
             pmin1[b] = lo;
             pmax1[b] = hi;
@@ -1320,12 +1316,8 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
             lo = pmin1[j];
             hi = pmax1[j];
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int x = __shfl_xor(lo, o), y = __shfl_xor(hi, o);
-            lo = x < lo ? x : lo;
-            hi = y > hi ? y : hi;
-        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
         if (lane == 0) {
             pmin2[b] = lo;
             pmax2[b] = hi;
@@ -1348,11 +1340,7 @@ __global__ __launch_bounds__(256) void block64_kernel(const Seg *segs, const int
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     int v = IS_MAX ? INT_MIN : INT_MAX;
     if (j < count) v = src[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int t = __shfl_xor(v, o);
-        v = IS_MAX ? (t > v ? t : v) : (t < v ? t : v);
-    }
+    v = IS_MAX ? wave_max(v) : wave_min(v);
     if ((threadIdx.x & 63) == 0) out[sg.off / 64 + (j >> 6)] = v;
 }
 
