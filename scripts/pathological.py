@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing check on adversarial inputs (GPU box): periodic texts, long runs and tiny alphabets at the sizes where the code
-paths switch (deferred address bits below 2 MiB, the fallback suffix sort above 512 KiB).  Checks the GPU round trip
+paths switch (deferred address bits below 2 MiB, the device-wide suffix sort above 512 KiB).  Checks the GPU round trip
 (the oracle needs many minutes on these) and prints the time of every one-shot Compress."""
 import os
 import sys
