@@ -153,6 +153,18 @@ def test_large_periodic_texts(amd):
         assert amd.Decompress(got[k], b"") == d, f"case {k}"
 
 
+def test_large_dictionary(amd):
+    """a dictionary of more than 2^19 bytes: its index is built by the device-wide sort too (compress.go:64)"""
+    rng = np.random.default_rng(9)
+    d = b"".join(amd.synth.blob(300 + k) for k in range(6))[:700000]  # MaxDictSize is 4 MiB (backref.go:11)
+    x = amd.synth.blob(301)[1000:30000] + bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) + amd.synth.blob(305)[:20000]
+    want = O.Compressor(d).compress(x)
+    c = amd.Compressor(d)
+    got = c.Compress(x)
+    assert got == want
+    assert amd.Decompress(got, d) == x
+
+
 def test_overlapped_sub_batches_give_the_same_bytes(amd, dict_naive):
     """mi355_lzss_ctx_set_overlap: the stages of 2..4 sub-batches run on concurrent streams; every segment's scratch
     (sort records, then its window index) must stay inside the segment's own region"""
