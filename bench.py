@@ -291,7 +291,7 @@ def main():
             sdata = b"".join(blobs[:16])                      # 2 MiB of the same synthetic stream
             comp = compress_amd.Compressor(dict_, device=local_rank)
             t0 = time.perf_counter()
-            spec = S.pack_stream(comp, sdata, 1000, 126976)
+            spec = S.pack_stream_native(comp, sdata, 1000, 126976)
             t_spec = time.perf_counter() - t0
             t0 = time.perf_counter()
             seq = S.pack_stream_sequential(comp, sdata[:300000], 1000, 126976)
@@ -300,7 +300,7 @@ def main():
                               "speculative_MBps": round(len(sdata) / t_spec / 1e6, 2), "speculative_bytes": len(sdata),
                               "sequential_MBps": round(300000 / t_seq / 1e6, 3), "sequential_bytes": 300000,
                               "blobs": len(spec),
-                              "equal_on_sequential_sample": S.pack_stream(comp, sdata[:300000], 1000, 126976) == seq}
+                              "equal_on_sequential_sample": S.pack_stream_native(comp, sdata[:300000], 1000, 126976) == seq}
         # ---- bit-exactness spot check + CPU baseline (oracle = checker / reported baseline only)
         if not args.no_cpu and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -28,6 +28,8 @@ SIGNATURES = {
     "mi355_lzss_write": (_i32, [_vp, _vp, _sz, _sz, C.c_uint, _vp, _sz, C.POINTER(_u64)]),
     "mi355_lzss_write_noalloc": (_i32, [_vp, _vp, _sz, _sz, C.c_uint, _vp, _sz, _vp, _vp, _vp]),
     "mi355_lzss_compressed_size": (_i32, [_vp, _vp, _sz, C.POINTER(_u64)]),
+    "mi355_lzss_pack_blob": (_i32, [_vp, _vp, _u64, _u32, _u64, _u32, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64),
+                                    C.POINTER(_i32)]),
     "mi355_lzss_compress_batch": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "mi355_lzss_decompress_batch": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "mi355_lzss_batch_create": (_i32, [_vp, _u32, _u64, C.POINTER(_vp)]),

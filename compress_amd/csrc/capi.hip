@@ -321,8 +321,10 @@ __global__ __launch_bounds__(256) void zero_out_kernel(uint8_t *out, const uint6
 
 // Enqueues on `s`: the blobs' bytes, their segment table, the layout kernel.  Host-side state of the batch is set
 // at once; the device side is ready when `s` has drained.  limit: blobs longer than this get E_INPUT_SIZE.
+// lens (optional): blob k is in[in_off[k], in_off[k] + lens[k]) - the ranges may then overlap (the candidate Writes of
+// mi355_lzss_pack_blob are prefixes of one another: their bytes go up once) and in_off has n_blobs entries.
 static int upload_async(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *in_off, uint32_t n_blobs,
-                        const uint32_t *starts, uint64_t limit, hipStream_t s) {
+                        const uint32_t *starts, uint64_t limit, hipStream_t s, const uint64_t *lens = nullptr) {
     int rc;
     uint64_t elems = 0;
     uint32_t max_n = 0;
@@ -331,22 +333,28 @@ static int upload_async(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *
     if ((rc = b->h_meta.ensure((size_t)std::max<uint32_t>(n_blobs, 1) * (sizeof(Seg) + 8))) != 0) return rc;
     Seg *hs = b->h_meta.as<Seg>();
     uint64_t *hsrc = reinterpret_cast<uint64_t *>(hs + n_blobs);
-    const uint64_t base = n_blobs ? in_off[0] : 0;
+    uint64_t base = n_blobs ? in_off[0] : 0, top = n_blobs && !lens ? in_off[n_blobs] : 0, coded_bytes = 0;
+    if (lens)
+        for (uint32_t k = 0; k < n_blobs; ++k) {
+            base = std::min(base, in_off[k]);
+            top = std::max(top, in_off[k] + lens[k]);
+        }
     for (uint32_t k = 0; k < n_blobs; ++k) {
-        if (in_off[k + 1] < in_off[k]) return fail(MI355_LZSS_E_ARG, "in_off must be non-decreasing");
-        uint64_t n = in_off[k + 1] - in_off[k];
+        if (!lens && in_off[k + 1] < in_off[k]) return fail(MI355_LZSS_E_ARG, "in_off must be non-decreasing");
+        uint64_t n = lens ? lens[k] : in_off[k + 1] - in_off[k];
         if (n > limit) {  // compress.go:473-475 (compress.go:390 for CompressedSize256k)
             b->h_pre_status[k] = MI355_LZSS_E_INPUT_SIZE;
             n = 0;
         }
         uint32_t st = starts ? starts[k] : 0;
         if (st > n) st = (uint32_t)n;
+        coded_bytes += n - st;
         b->h_segs[k] = hs[k] = Seg{elems, (uint32_t)n, st};
         hsrc[k] = in_off[k] - base;
         elems += seg_stride(n);
         max_n = std::max<uint32_t>(max_n, (uint32_t)n);
     }
-    const uint64_t flat_bytes = n_blobs ? in_off[n_blobs] - base : 0;
+    const uint64_t flat_bytes = n_blobs ? top - base : 0;
     if ((rc = batch_reserve(b, std::max<uint32_t>(n_blobs, 1), std::max<uint64_t>(elems, SEG_ALIGN))) != 0) return rc;
     if ((rc = b->flat.ensure((size_t)flat_bytes + 16)) != 0) return rc;
     if (max_n + 1 > SA_BITMAP_MAX_N) {  // the device-wide sort of large texts (sa_large.hip) keeps two more arrays in HBM
@@ -371,7 +379,7 @@ static int upload_async(mi355_lzss_batch *b, const uint8_t *in, const uint64_t *
     b->n_blobs = n_blobs;
     b->max_n = max_n;
     b->used_elems = elems;
-    b->flat_bytes = flat_bytes;
+    b->flat_bytes = lens ? std::max(flat_bytes, coded_bytes) : flat_bytes;  // (sizes the output buffer: what gets encoded)
     b->have_sizes = false;
     return 0;
 }
@@ -1008,6 +1016,126 @@ extern "C" int mi355_lzss_compressed_size(mi355_lzss_ctx *ctx, const uint8_t *d,
     uint64_t sz = 0;
     const int rc = mi355_lzss_compressed_size_batch(ctx, d ? d : (const uint8_t *)"", off2, 1, &sz, nullptr);
     if (rc == 0 && size) *size = sz;
+    return rc;
+}
+
+// ---- one size-capped blob from a stream, its candidate Writes as batches -------------------------
+// bits [0, nbits) of src (most significant bit first) appended to dst at bit position pos
+static void append_bits(std::vector<uint8_t> &dst, uint64_t &pos, const uint8_t *src, uint64_t nbits) {
+    if (nbits == 0) return;
+    dst.resize((size_t)((pos + nbits + 7) / 8), 0);
+    const unsigned sh = (unsigned)(pos & 7);
+    const uint64_t byte = pos >> 3, nbytes = (nbits + 7) / 8;
+    for (uint64_t k = 0; k < nbytes; ++k) {
+        uint8_t v = src[k];
+        if (k == nbytes - 1 && (nbits & 7)) v &= (uint8_t)(0xFF00u >> (nbits & 7));
+        dst[(size_t)(byte + k)] |= (uint8_t)(v >> sh);
+        if (sh && byte + k + 1 < dst.size()) dst[(size_t)(byte + k + 1)] |= (uint8_t)(v << (8 - sh));
+    }
+    pos += nbits;
+}
+
+extern "C" int mi355_lzss_pack_blob(mi355_lzss_ctx *ctx, const uint8_t *data, uint64_t n, uint32_t chunk, uint64_t out_max,
+                                    uint32_t lookahead, uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *chunks,
+                                    int *needs_loop) {
+    if (!ctx || (n && !data) || !out_len || !chunks || !needs_loop || (out_cap && !out))
+        return fail(MI355_LZSS_E_ARG, "null argument");
+    if (chunk == 0 || lookahead == 0 || out_max < LZSS_HEADER_SIZE) return fail(MI355_LZSS_E_ARG, "chunk, lookahead and out_max must be positive");
+    if (ctx->decode_only) return fail(MI355_LZSS_E_ARG, "the context was created for decompression only");
+    *out_len = 0;
+    *chunks = 0;
+    *needs_loop = 0;
+    int rc;
+    if ((rc = set_device(ctx)) != 0) return rc;
+    mi355_lzss_batch *b = nullptr;
+    if ((rc = pool_acquire(ctx, &b)) != 0) return rc;
+    std::vector<uint8_t> acc;  // the blob's phrase bits so far
+    uint64_t pos = 0;          // bits in acc
+    uint64_t total = 0;        // accepted phrase bits (pos, but for the pad bits a Revert leaves behind)
+    uint64_t j = 0;            // accepted chunks
+    auto finish = [&](uint64_t k) -> int {
+        const uint64_t len = LZSS_HEADER_SIZE + (pos + 7) / 8;
+        *out_len = len;
+        *chunks = k;
+        if (len > out_cap) return fail(MI355_LZSS_E_CAPACITY, "the blob needs %llu bytes", (unsigned long long)len);
+        out[0] = (uint8_t)(LZSS_VERSION >> 8);
+        out[1] = (uint8_t)(LZSS_VERSION & 0xFF);
+        out[2] = 0;
+        if (len > LZSS_HEADER_SIZE) memcpy(out + LZSS_HEADER_SIZE, acc.data(), (size_t)(len - LZSS_HEADER_SIZE));
+        return 0;
+    };
+    auto run = [&]() -> int {
+        std::vector<uint8_t> streams;
+        std::vector<uint64_t> off, plen, soff, nbits;
+        std::vector<uint32_t> starts, lens;
+        std::vector<int32_t> status;
+        for (;;) {
+            // candidate Writes j + 1 .. j + look (the loop starts a Write only while bytes are left).  After the first
+            // batch the blob's own bits per chunk predict where the cap falls: the next batch reaches just past it
+            uint64_t look = lookahead;
+            if (j && total) {
+                const double left = (double)(((int64_t)out_max - LZSS_HEADER_SIZE) * 8 - (int64_t)total);
+                const int64_t est = (int64_t)(left / ((double)total / (double)j) * 1.04) + 3;
+                look = (uint64_t)std::max<int64_t>(4, std::min<int64_t>(4 * (int64_t)lookahead, est));
+            }
+            off.clear();
+            plen.clear();
+            starts.clear();
+            for (uint64_t t = 0; t < look; ++t) {
+                const uint64_t s = (j + t) * (uint64_t)chunk;
+                if (s >= n) break;
+                const uint64_t e = std::min<uint64_t>(s + chunk, n);
+                if (e > LZSS_MAX_INPUT_SIZE) break;  // Write would fail there (compress.go:473); the loop ends before it
+                off.push_back(0);  // every candidate's inBuf is a prefix of the stream's rest: the bytes go up once
+                plen.push_back(e);
+                starts.push_back((uint32_t)s);
+            }
+            const uint32_t cnt = (uint32_t)starts.size();
+            if (cnt == 0) return finish(j);
+            int r;
+            if ((r = upload_async(b, data, off.data(), cnt, starts.data(), LZSS_MAX_INPUT_SIZE, b->stream, plen.data())) != 0) return r;
+            if ((r = mi355_lzss_batch_compress(b, 0)) != 0) return r;
+            lens.assign(cnt, 0);
+            nbits.assign(cnt, 0);
+            uint64_t tot = 0;
+            if ((r = mi355_lzss_batch_sizes(b, lens.data(), nbits.data(), &tot)) != 0) return r;
+            bool have = false;
+            for (uint32_t t = 0; t < cnt; ++t) {
+                const uint64_t new_total = total + nbits[t];
+                const uint64_t new_len = LZSS_HEADER_SIZE + (new_total + 7) / 8;
+                const uint64_t uncompressed = (j + t + 1) * (uint64_t)chunk + 3;
+                if (new_len >= out_max && uncompressed <= out_max && new_len > uncompressed) {
+                    *needs_loop = 1;  // the loop would call ConsiderBypassing here (compress_test.go:343-346)
+                    return 0;
+                }
+                if (!have) {
+                    soff.assign(cnt + 1, 0);
+                    for (uint32_t k = 0; k < cnt; ++k) soff[k + 1] = soff[k] + lens[k];
+                    streams.assign((size_t)soff[cnt] + 16, 0);
+                    status.assign(cnt, 0);
+                    if ((r = mi355_lzss_batch_download(b, streams.data(), soff.data(), status.data())) != 0) return r;
+                    for (uint32_t k = 0; k < cnt; ++k)
+                        if (status[k] != 0) return fail(status[k], "candidate write %u failed", k);
+                    have = true;
+                }
+                const uint8_t *st = streams.data() + soff[t];
+                if (new_len > out_max) {
+                    // Revert: the blob ends before this chunk.  outBuf.Truncate(lastOutLen) (compress.go:341) keeps the
+                    // re-opened last byte as the reverted Write left it, so the pad bits of the blob are the first
+                    // bits of the reverted chunk's phrases, not zeros
+                    const uint64_t pad = std::min<uint64_t>((8 - (total & 7)) & 7, nbits[t]);
+                    append_bits(acc, pos, st, pad);
+                    return finish(j + t);
+                }
+                append_bits(acc, pos, st, nbits[t]);
+                total = new_total;
+                if (new_len >= out_max) return finish(j + t + 1);
+            }
+            j += cnt;
+        }
+    };
+    rc = run();
+    pool_release(ctx, b);
     return rc;
 }
 

@@ -8,10 +8,13 @@ is "inBuf = data[i0 : i0 + j*chunk], start = (j-1)*chunk" (the `starts` of mi355
 runs `lookahead` of them per batch - the same total work as the sequential loop, as batch work - and replays the
 loop's decisions on the bit counts.  The blobs are byte-identical to the sequential loop's (tests/test_gpu_stream.py).
 """
+import ctypes as C
+
 import numpy as np
 
+from . import _lib
 from .batch import Batch
-from .lzss import Compressor, Header, HeaderSize, Version
+from .lzss import Compressor, Header, HeaderSize, LzssError, Version
 
 
 def _sequential_one(compressor: Compressor, data: bytes, i0: int, chunk: int, out_max: int):
@@ -133,5 +136,33 @@ def pack_stream(compressor: Compressor, data: bytes, chunk: int, out_max: int, l
             i0 += k * chunk
     finally:
         ws.close()
+        compressor.Reset()
+    return res
+
+
+def pack_stream_native(compressor: Compressor, data: bytes, chunk: int, out_max: int, lookahead: int = 64):
+    """pack_stream through the C entry point mi355_lzss_pack_blob (the path of a Go / C++ caller): one call per blob,
+    the rare blobs in which ConsiderBypassing would fire run the loop on `compressor`."""
+    data = bytes(data)
+    arr = np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, np.uint8)
+    out = np.zeros(out_max + 16, dtype=np.uint8)
+    out_len, chunks, loop = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+    lib = _lib.lib()
+    res, i0 = [], 0
+    try:
+        while i0 < len(data):
+            rc = lib.mi355_lzss_pack_blob(compressor._ctx.h, arr[i0:].ctypes.data, len(data) - i0, chunk, out_max, lookahead,
+                                          out.ctypes.data, out.size, C.byref(out_len), C.byref(chunks), C.byref(loop))
+            if rc != 0:
+                raise LzssError(_lib.last_error(), rc)
+            if loop.value:
+                blob, k = _sequential_one(compressor, data, i0, chunk, out_max)
+            else:
+                blob, k = out[:out_len.value].tobytes(), int(chunks.value)
+            if k <= 0:
+                raise ValueError("a single chunk does not fit the output cap")
+            res.append((blob, min(i0 + k * chunk, len(data)) - i0))
+            i0 += k * chunk
+    finally:
         compressor.Reset()
     return res

@@ -454,6 +454,71 @@ func (c *Compressor) CompressedSizes256k(blobs [][]byte) ([]int, error) {
 	return res, nil
 }
 
+// PackedBlob is one blob of PackStream: its bytes (what Bytes() holds when the loop stops) and the input it covers.
+type PackedBlob struct {
+	Bytes    []byte
+	Consumed int
+}
+
+// PackStream fills size-capped blobs from a stream exactly like the Write / Revert loop of the reference's callers
+// (lzss/compress_test.go:337-353: Write chunk after chunk while Len() < outMax, Revert the chunk that overshot), but
+// runs the candidate Writes of a blob as device batches (mi355_lzss_pack_blob, lookahead of them at a time).  Blobs in
+// which ConsiderBypassing would fire run the loop itself on c.  No counterpart in the reference.
+func (c *Compressor) PackStream(data []byte, chunk, outMax, lookahead int) ([]PackedBlob, error) {
+	var res []PackedBlob
+	out := make([]byte, outMax+16)
+	for i0 := 0; i0 < len(data); {
+		var outLen, chunks C.uint64_t
+		var needsLoop C.int
+		rest := data[i0:]
+		if rc := C.mi355_lzss_pack_blob(c.ctx, ptr(rest), C.uint64_t(len(rest)), C.uint32_t(chunk), C.uint64_t(outMax),
+			C.uint32_t(lookahead), ptr(out), C.uint64_t(len(out)), &outLen, &chunks, &needsLoop); rc != 0 {
+			return nil, lastError(rc)
+		}
+		var blob []byte
+		k := int(chunks)
+		if needsLoop != 0 { // the loop of compress_test.go:337-353 on this compressor
+			c.Reset()
+			i := i0
+			for i < len(data) && c.Len() < outMax {
+				end := i + chunk
+				if end > len(data) {
+					end = len(data)
+				}
+				if _, err := c.Write(data[i:end]); err != nil {
+					return nil, err
+				}
+				uncompressed := i + chunk - i0 + 3
+				if c.Len() >= outMax && uncompressed <= outMax && c.Len() > uncompressed {
+					c.ConsiderBypassing()
+				}
+				i += chunk
+			}
+			if c.Len() > outMax {
+				if err := c.Revert(); err != nil {
+					return nil, err
+				}
+				i -= chunk
+			}
+			blob = append([]byte(nil), c.Bytes()...)
+			k = (i - i0) / chunk
+		} else {
+			blob = append([]byte(nil), out[:int(outLen)]...)
+		}
+		if k <= 0 {
+			return nil, errors.New("a single chunk does not fit the output cap")
+		}
+		consumed := k * chunk
+		if i0+consumed > len(data) {
+			consumed = len(data) - i0
+		}
+		res = append(res, PackedBlob{Bytes: blob, Consumed: consumed})
+		i0 += k * chunk
+	}
+	c.Reset()
+	return res, nil
+}
+
 // CompressBatchMulti is CompressBatch over several compressors, one per GPU of the node (create them with
 // Device = 0 .. n-1 and the same dictionary): contiguous blob ranges balanced by bytes, one host thread per device,
 // no collective (mi355_lzss_compress_batch_multi).  No counterpart in the reference.

@@ -144,6 +144,21 @@ int mi355_lzss_decompress_batch_multi(mi355_lzss_ctx *const *ctxs, int n_ctx, co
  * the bytes */
 int mi355_lzss_partition(const uint64_t *off, uint32_t n_blobs, int n_parts, uint32_t *first);
 
+/* Filling a size-capped blob from a stream: the Write / Revert loop of the reference's callers
+ * (lzss/compress_test.go:337-353: Write chunk after chunk while Len() < out_max, Revert the chunk
+ * that overshot).  Every Write re-indexes the whole inBuf (compress.go:113-116), so on a GPU the
+ * loop is one short job per chunk; the bits a chunk adds depend only on the blob's bytes before and
+ * inside it, so this call runs the Writes of `lookahead` candidate chunk counts as one batch and
+ * replays the loop's decisions on their bit counts.  data[0, n) is the rest of the stream.  Out: the
+ * blob (header included), byte for byte what the loop leaves in Bytes() - the pad bits a Revert
+ * leaves behind (outBuf.Truncate, compress.go:341) included -, and the number of chunks it holds.
+ * *needs_loop = 1 (nothing written): ConsiderBypassing would fire in this blob (compress_test.go:
+ * 343-346); run the loop itself for it (mi355_lzss_write and the host mirror's state machine).
+ * Thread-safe per ctx (pooled workspaces).  compress_amd/stream.py is the same in Python. */
+int mi355_lzss_pack_blob(mi355_lzss_ctx *ctx, const uint8_t *data, uint64_t n, uint32_t chunk,
+                         uint64_t out_max, uint32_t lookahead, uint8_t *out, uint64_t out_cap,
+                         uint64_t *out_len, uint64_t *chunks, int *needs_loop);
+
 /* ---- device-resident batches (what bench.py times) -------------------------------------------
  * The same two operations split into upload / run / download so that a caller can keep inputs
  * and outputs resident in HBM and time the device work alone.  A batch owns all device memory

@@ -33,6 +33,7 @@ def test_pack_stream_equals_the_reference_loop(dict_naive, average_block, chunk,
     assert [n for _, n in got] == [n for _, n in want]
     assert [b for b, _ in got] == [b for b, _ in want]
     assert sum(n for _, n in got) == len(data)
+    assert stream.pack_stream_native(comp, data, chunk, out_max, lookahead) == want  # the same through the C ABI
     off = 0
     for blob, n in got[:3]:  # the blobs decode to consecutive pieces of the stream (compress_test.go:358)
         assert compress_amd.Decompress(blob, dict_naive) == data[off:off + n]
@@ -48,6 +49,7 @@ def test_pack_stream_with_incompressible_stretches(dict_naive):
     want = stream.pack_stream_sequential(OracleCompressor(dict_naive), data, 1000, 5000)
     got = stream.pack_stream(compress_amd.Compressor(dict_naive), data, 1000, 5000, 16)
     assert got == want
+    assert stream.pack_stream_native(compress_amd.Compressor(dict_naive), data, 1000, 5000, 16) == want
 
 
 def test_pack_stream_at_config4_cap(dict_naive):
@@ -62,3 +64,4 @@ def test_pack_stream_at_config4_cap(dict_naive):
     assert [n for _, n in got] == [n for _, n in want]
     assert got == want
     assert len(got) == 2 and 126976 - 1000 <= len(got[0][0]) <= 126976   # one more 1000-byte chunk would not have fitted
+    assert stream.pack_stream_native(compress_amd.Compressor(dict_naive), data, 1000, 126976) == want
