@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--stage-steps", type=int, default=2, help="extra untimed steps (one part) for the per-kernel times")
     ap.add_argument("--pipe-repeats", type=int, default=1, help="the batch repeated this many times through the "
                     "host-buffer pipeline (transfer-inclusive figure); 0 = skip")
-    ap.add_argument("--chunk-blobs", type=int, default=1250, help="blobs per chunk of that pipeline")
+    ap.add_argument("--chunk-blobs", type=int, default=1536, help="blobs per chunk of that pipeline")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's parallel leg (0 = min(16, cores))")
     args = ap.parse_args()
 
@@ -194,7 +194,7 @@ def main():
     dec_ok = back == blobs
 
     # ---- transfer-inclusive: the same blobs from pinned HOST buffers through mi355_lzss_compress_batch, which pipelines
-    #      chunks of 1250 blobs (upload of chunk k+1 and download of chunk k-1 overlap the kernels of chunk k); timed
+    #      chunks of 1536 blobs (upload of chunk k+1 and download of chunk k-1 overlap the kernels of chunk k); timed
     #      around the whole call, outputs land in the caller's CSR layout on the host
     pipe = None
     if args.pipe_repeats > 0:

@@ -57,7 +57,8 @@ int  mi355_lzss_ctx_set_overlap(mi355_lzss_ctx *ctx, int parts);
 /* Tuning knob with no counterpart in the reference: the host-buffer batch entry points
  * (mi355_lzss_compress_batch, ..._multi) cut a batch into chunks of about this many input bytes and run
  * them as a pipeline - chunk k+1 goes up and chunk k-1 comes down while chunk k computes.  Default
- * 160 MiB (1250 blobs of 128 KiB); results do not depend on it. */
+ * 200 MiB; a chunk that is not the last takes a whole number of rounds of the suffix sort's resident
+ * workgroups (2 per CU: 1536 blobs of 128 KiB on an MI355X).  Results do not depend on it. */
 int  mi355_lzss_ctx_set_chunk_bytes(mi355_lzss_ctx *ctx, uint64_t bytes);
 /* Pinned host memory (hipHostMalloc) for callers that want their batch buffers to move by DMA: with
  * `in` / `out` of the batch entry points allocated here the copies overlap with the kernels.  Pageable
