@@ -123,6 +123,9 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint3
 // wave-wide load whose lanes hit 64 different lines costs ~250 cycles of it); here the only global traffic left is the
 // suffix array in (prefetched one step ahead) and the LCP array out, both streams.
 constexpr int LCPL_THREADS = 1024;
+#ifndef LCP_WIDE
+#define LCP_WIDE 1   // compare steps of 16 bytes (0: 8 bytes)
+#endif
 constexpr uint32_t LCP_LDS_MAX_N = 150000;
 __global__ __launch_bounds__(LCPL_THREADS) void lcp_lds_kernel(const Seg *segs, BatchIndex ix) {
     extern __shared__ uint32_t s_t32[];  // the text as words, zero padded (the 64 zero bytes behind it come along)
@@ -184,6 +187,26 @@ __global__ __launch_bounds__(LCPL_THREADS) void lcp_lds_kernel(const Seg *segs, 
                         l = (uint32_t)(q < lim ? q : lim);
                     } else {
                         int o = r > 8 ? r : 8;
+#if LCP_WIDE
+                        while (o < lim) {  // 16 bytes per round trip: five words of each suffix (12.9 vs 13.7 ms; 32 bytes: 13.2)
+                            const uint32_t pa = (uint32_t)a + (uint32_t)o, pb = (uint32_t)sak + (uint32_t)o;
+                            const uint32_t ia = pa >> 2, sa_ = pa & 3u, ib = pb >> 2, sb_ = pb & 3u;
+                            const uint32_t a0 = s_t32[ia], a1 = s_t32[ia + 1], a2 = s_t32[ia + 2], a3 = s_t32[ia + 3], a4 = s_t32[ia + 4];
+                            const uint32_t b0 = s_t32[ib], b1 = s_t32[ib + 1], b2 = s_t32[ib + 2], b3 = s_t32[ib + 3], b4 = s_t32[ib + 4];
+                            const uint32_t x0 = __builtin_amdgcn_alignbyte(a1, a0, sa_) ^ __builtin_amdgcn_alignbyte(b1, b0, sb_);
+                            const uint32_t x1 = __builtin_amdgcn_alignbyte(a2, a1, sa_) ^ __builtin_amdgcn_alignbyte(b2, b1, sb_);
+                            const uint32_t x2 = __builtin_amdgcn_alignbyte(a3, a2, sa_) ^ __builtin_amdgcn_alignbyte(b3, b2, sb_);
+                            const uint32_t x3 = __builtin_amdgcn_alignbyte(a4, a3, sa_) ^ __builtin_amdgcn_alignbyte(b4, b3, sb_);
+                            if (x0 | x1 | x2 | x3) {
+                                if (x0) o += (int)(__builtin_ctz(x0) >> 3);
+                                else if (x1) o += 4 + (int)(__builtin_ctz(x1) >> 3);
+                                else if (x2) o += 8 + (int)(__builtin_ctz(x2) >> 3);
+                                else o += 12 + (int)(__builtin_ctz(x3) >> 3);
+                                break;
+                            }
+                            o += 16;
+                        }
+#else
                         while (o < lim) {
                             const uint64_t y = ld8s((uint32_t)a + (uint32_t)o) ^ ld8s((uint32_t)sak + (uint32_t)o);
                             if (y) {
@@ -192,6 +215,7 @@ __global__ __launch_bounds__(LCPL_THREADS) void lcp_lds_kernel(const Seg *segs, 
                             }
                             o += 8;
                         }
+#endif
                         l = (uint32_t)(o < lim ? o : lim);
                     }
                 }
