@@ -7,9 +7,11 @@
 // emission of every Write run on the GPU (mi355_lzss_write); only the stream state of compress.go:91-129,
 // 289-367 (header, re-opened last byte, Revert bookkeeping) lives here.  Header-only; link libmi355_lzss.so.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/lzss_format.h"
@@ -175,6 +177,45 @@ class Compressor {
         uint64_t size = 0;
         check(mi355_lzss_compressed_size(ctx_, d.data(), d.size(), &size));
         return size_t(size);
+    }
+
+    // Filling size-capped blobs from a stream: the Write / Revert loop of lzss/compress_test.go:337-353 with the
+    // candidate Writes of a blob run as device batches (mi355_lzss_pack_blob); blobs in which ConsiderBypassing would
+    // fire run the loop itself.  Returns (blob bytes, input bytes it covers) per blob.  No counterpart in the reference.
+    std::vector<std::pair<Bytes, size_t>> PackStream(const Bytes &data, size_t chunk, size_t outMax, unsigned lookahead = 64) {
+        std::vector<std::pair<Bytes, size_t>> res;
+        Bytes buf(outMax + 16);
+        for (size_t i0 = 0; i0 < data.size();) {
+            uint64_t len = 0, chunks = 0;
+            int loop = 0;
+            check(mi355_lzss_pack_blob(ctx_, data.data() + i0, data.size() - i0, (uint32_t)chunk, outMax, lookahead, buf.data(),
+                                       buf.size(), &len, &chunks, &loop));
+            Bytes blob;
+            size_t k = size_t(chunks);
+            if (loop) {
+                Reset();
+                size_t i = i0;
+                while (i < data.size() && Len() < outMax) {
+                    Write(data.data() + i, std::min(chunk, data.size() - i));
+                    const size_t uncompressed = i + chunk - i0 + 3;
+                    if (Len() >= outMax && uncompressed <= outMax && Len() > uncompressed) ConsiderBypassing();
+                    i += chunk;
+                }
+                if (Len() > outMax) {
+                    Revert();
+                    i -= chunk;
+                }
+                blob = out_;
+                k = (i - i0) / chunk;
+            } else {
+                blob.assign(buf.begin(), buf.begin() + (long)len);
+            }
+            if (k == 0) throw Error("a single chunk does not fit the output cap");
+            res.emplace_back(blob, std::min(i0 + k * chunk, data.size()) - i0);
+            i0 += k * chunk;
+        }
+        Reset();
+        return res;
     }
 
     mi355_lzss_ctx *ctx() { return ctx_; }

@@ -25,6 +25,8 @@ int main(int argc, char **argv) {
         put(out, one);
         c.Reset();
         const size_t chunk = 1000, cap = 4000;
+        const auto packed = c.PackStream(data, chunk, cap, 8);  // must equal the loop below, blob for blob
+        size_t blob_no = 0;
         for (size_t i0 = 0; i0 < data.size();) {
             size_t i = i0;
             for (; i < data.size() && c.Len() < cap; i += chunk)
@@ -34,8 +36,18 @@ int main(int argc, char **argv) {
                 i -= chunk;
             }
             put(out, c.GetBytes());
+            if (blob_no >= packed.size() || packed[blob_no].first != c.GetBytes() ||
+                packed[blob_no].second != std::min(i, data.size()) - i0) {
+                fprintf(stderr, "PackStream differs from the Write / Revert loop at blob %zu\n", blob_no);
+                return 3;
+            }
+            ++blob_no;
             c.Reset();
             i0 = i;
+        }
+        if (blob_no != packed.size()) {
+            fprintf(stderr, "PackStream made %zu blobs, the loop %zu\n", packed.size(), blob_no);
+            return 3;
         }
         put(out, lzss::Decompress(one, dict));
     } catch (const std::exception &e) {
