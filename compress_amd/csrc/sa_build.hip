@@ -92,10 +92,15 @@ template <int DB> struct SaInit {
 #define SA_USE_MTAB 1
 #endif
 #ifdef SA_PROFILE  // per-phase clocks of workgroup 0 (debug builds only)
+__device__ long long g_rg[8];
+#define RG(i) { if (INITIAL) { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); if (blockIdx.x == 0 && tid == 0) g_rg[i] += t_ - rg_last; rg_last = t_; } }
+#define RG_DECL long long rg_last = clock64();
 #define SA_PROF_DECL long long prof_acc[24] = {}; long long prof_last = clock64();
 #define SA_PROF(i) { __builtin_amdgcn_s_waitcnt(0); const long long t_ = clock64(); prof_acc[i] += t_ - prof_last; prof_last = t_; }
-#define SA_PROF_PRINT if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x / 64 < 2) { printf("w%d init: ld %lld rank %lld prep %lld put %lld | regI %lld | S1: ld %lld gath %lld rank %lld prep %lld put %lld | S2: ld %lld rank %lld prep %lld put %lld | D %lld | other %lld | late build %lld passes %lld | finish init %lld rounds %lld | setup %lld sweep %lld\n", threadIdx.x / 64, prof_acc[0], prof_acc[1], prof_acc[2], prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11], prof_acc[12], prof_acc[13], prof_acc[14], prof_acc[15], prof_acc[16], prof_acc[17], prof_acc[19], prof_acc[18], prof_acc[20], prof_acc[21]); }
+#define SA_PROF_PRINT if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x / 64 < 2) { printf("w%d init: ld %lld rank %lld prep %lld put %lld | regI %lld | S1: ld %lld gath %lld rank %lld prep %lld put %lld | S2: ld %lld rank %lld prep %lld put %lld | D %lld | other %lld | late build %lld passes %lld | finish init %lld rounds %lld | setup %lld sweep %lld\n", threadIdx.x / 64, prof_acc[0], prof_acc[1], prof_acc[2], prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6], prof_acc[7], prof_acc[8], prof_acc[9], prof_acc[10], prof_acc[11], prof_acc[12], prof_acc[13], prof_acc[14], prof_acc[15], prof_acc[16], prof_acc[17], prof_acc[19], prof_acc[18], prof_acc[20], prof_acc[21]); if (threadIdx.x == 0) printf("regI: loop %lld load %lld flags %lld barrier %lld lists %lld write %lld\n", g_rg[0], g_rg[1], g_rg[2], g_rg[3], g_rg[4], g_rg[5]); }
 #else
+#define RG(i)
+#define RG_DECL
 #define SA_PROF_DECL
 #define SA_PROF(i)
 #define SA_PROF_PRINT
@@ -514,7 +519,15 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
     int tileK = -1, tileS = -1;
     uint32_t rem = 0;
     int par = 0;
+    RG_DECL
+    uint64_t nx[SA_K];
+#pragma unroll
+    for (int s = 0; s < SA_K; ++s) {
+        const uint32_t u = (uint32_t)w * SA_WSPAN + s * 64 + lane;
+        nx[s] = (INITIAL && u < m) ? rec[u] : 0;
+    }
     for (uint32_t t0 = 0; t0 < m; t0 += SA_TILE, par ^= 1) {
+        RG(0)
         const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
         uint64_t key[SA_K];
         int p[SA_K];
@@ -524,11 +537,12 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             key[s] = 0;
             p[s] = 0;
             if (u < m) {
-                const uint64_t r = rec[u];
+                const uint64_t r = INITIAL ? nx[s] : rec[u];
                 p[s] = (int)(r & ((1u << RS) - 1u));
                 key[s] = r >> RS;
             }
         }
+        RG(1)
         // neighbours across the wave's span (uniform loads)
         uint64_t pkey = 0, nkey = 0;
         const uint32_t un = wb + SA_WSPAN;
@@ -579,7 +593,9 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             cy.a[par][w] = runK;
             cy.b[par][w] = runS;
         }
+        RG(2)
         __syncthreads();
+        RG(3)
         int cinK = tileK, cinS = tileS;
         for (int ww = 0; ww < SAM_WAVES; ++ww) {
             const int a = cy.a[par][ww], b = cy.b[par][ww];
@@ -609,6 +625,16 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
                 const uint64_t heads = __ballot(fsz[s] > 0);
                 const uint64_t lS = bS[s] & lem;  // group starts of this step at or below this lane
                 if (lS && ((heads >> (63 - (int)__builtin_clzll(lS))) & 1)) fl[s] |= 8;
+            }
+        }
+        RG(4)
+        // the next tile's records, in flight while this tile is written (a tile used to start by waiting ~10 us for
+        // them; the keys are dead by now - issued any earlier the loads cost 26 spilled registers: 64.5 vs 61.7 ms)
+        if (INITIAL && t0 + SA_TILE < m) {
+#pragma unroll
+            for (int s = 0; s < SA_K; ++s) {
+                const uint32_t u = wb + SA_TILE + s * 64 + lane;
+                nx[s] = u < m ? rec[u] : 0;
             }
         }
 #pragma unroll
@@ -660,6 +686,7 @@ __device__ inline uint32_t sa_regroup(const SaLds<DB> &L, SaCarry &cy, const uin
             }
             rem += (uint32_t)__popcll(__ballot(valid && !sgl));
         }
+        RG(5)
     }
     if (lane == 0) cy.wcount[w] = (int)rem;
     __syncthreads();
