@@ -1273,10 +1273,13 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
     const int cbits = nch > 1 ? 32 - __clz(nch - 1) : 0;  // bits of a chunk number
     hist_clear(sh, tid);
     __syncthreads();
+    // (both sweeps load a step's suffix-array entries one step ahead: a wave's steps were one memory latency each)
+    int sa_next = cbeg + lane < cend ? SA[cbeg + lane] : 0;
     for (uint32_t k0 = cbeg; k0 < cend; k0 += 64) {
         const uint32_t k = k0 + lane;
         const bool active = k < cend;
-        const int c = active ? (SA[k] >> WIN_SHIFT) : 0;
+        const int c = active ? (sa_next >> WIN_SHIFT) : 0;
+        sa_next = k + 64 < cend ? SA[k + 64] : 0;
         const uint64_t peers = match_digit_n(c, __ballot(active), cbits);
         if (active && (peers & lanemask_lt(lane)) == 0) sh.hist[w][c] += __popcll(peers);
     }
@@ -1292,10 +1295,12 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
     __syncthreads();
     int32_t *hrow = sh.hist[w];
     uint16_t *cdir = ix.cdir + (sg.off / 64) * ix.nch;
+    sa_next = cbeg + lane < cend ? SA[cbeg + lane] : 0;
     for (uint32_t k0 = cbeg; k0 < cend; k0 += 64) {
         const uint32_t k = k0 + lane;
         const bool active = k < cend;
-        const int p = active ? SA[k] : 0;
+        const int p = active ? sa_next : 0;
+        sa_next = k + 64 < cend ? SA[k + 64] : 0;
         const int c = p >> WIN_SHIFT;
         // directory: entries of every chunk before rank k0 (k0 == 1 + 64 b; the waves' rank ranges are whole blocks)
         for (int cc = lane; cc < nch; cc += 64) cdir[((k0 - 1) >> 6) * ix.nch + cc] = (uint16_t)(hrow[cc] - (cc << WIN_SHIFT));
@@ -1324,10 +1329,12 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
     int32_t *pmin1 = ix.pmin1 + sg.off / 64, *pmax1 = ix.pmax1 + sg.off / 64;
     int32_t *pmin2 = ix.pmin2 + sg.off / 64, *pmax2 = ix.pmax2 + sg.off / 64;
     const uint32_t nb1 = (n + 63) / 64, nb2 = (nb1 + 63) / 64;
+    int e_next = (uint32_t)w * 64 + lane < n ? E[(uint32_t)w * 64 + lane] : 0;
     for (uint32_t b = w; b < nb1; b += SA_WAVES) {
         const uint32_t j = b * 64 + lane;
         int lo = INT_MAX, hi = INT_MIN;
-        if (j < n) lo = hi = E[j] & emask;
+        if (j < n) lo = hi = e_next & emask;
+        e_next = j + 64 * SA_WAVES < n ? E[j + 64 * SA_WAVES] : 0;
         lo = wave_min(lo);
         hi = wave_max(hi);
         if (lane == 0) {
