@@ -70,6 +70,7 @@ void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, con
 void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream);
 // skip_unqueried: leave out positions the walk provably never asks about (deep inside a run of >= 160
 // equal bytes, compress.go:180-218); their result is then RES_NONE
+// (launch_match_head also fills ix.dlb, the dictionary brackets launch_match reads: call it first)
 void launch_match_head(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
                        uint32_t *d_res, hipStream_t stream);
 void launch_match(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, const DictView &dict,
