@@ -7,7 +7,9 @@ make -s
 mkdir -p ../variants
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
-  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $flags -c ${VSRC:-sa_build.hip} -o /tmp/var_$name.o
+  extra=""
+  if [ "${VSRC:-sa_build.hip}" = sa_build.hip ]; then extra="-mllvm -amdgpu-atomic-optimizer-strategy=None"; fi  # as in the Makefile
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $extra $flags -c ${VSRC:-sa_build.hip} -o /tmp/var_$name.o
   objs=""
   for o in sa_build.o sa_large.o match.o emit.o decompress.o capi.o; do
     if [ "$o" = "$(basename ${VSRC:-sa_build.hip} .hip).o" ]; then objs="$objs /tmp/var_$name.o"; else objs="$objs $o"; fi
