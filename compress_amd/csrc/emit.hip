@@ -94,7 +94,7 @@ __global__ __launch_bounds__(DECIDE_THREADS) void decide_kernel(const Seg *segs,
     __shared__ uint32_t s_pb_all[DECIDE_THREADS / 64][2][TILE];
     const Seg sg = segs[blockIdx.y];
     const int n = (int)sg.n;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_index((int)threadIdx.x);
     const int tbase = (int)((blockIdx.x * (DECIDE_THREADS / 64) + w) * TILE), tend = tbase + TILE;
     if (tbase >= n || tend <= (int)sg.start) return;
     uint32_t (*s_pb)[TILE] = s_pb_all[w];

@@ -88,6 +88,10 @@ __device__ inline uint32_t xcd_block(uint32_t b, uint32_t nblk) { return (b & 7u
 inline uint32_t xcd_grid(uint64_t blocks) { return (uint32_t)((blocks + 7) / 8 * 8); }
 
 // ---- wave-level data movement without the LDS crossbar ------------------------------------------------
+// A thread's wave inside its workgroup as a value the compiler KNOWS to be wave-uniform (an SGPR): derived from
+// threadIdx alone it counts as divergent, and every loop bounded by it (a wave's share of a sweep) is compiled with
+// exec masking, its ballots kept in VGPRs and its loads waited for at once.
+__device__ inline int wave_index(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
 // The value of lane `l` (wave-uniform) in every lane: one v_readlane instead of a trip through the LDS crossbar
 // (__shfl compiles to ds_bpermute_b32 and a wait for it).
 __device__ inline int lane_value(int v, int l) { return __builtin_amdgcn_readlane(v, l); }

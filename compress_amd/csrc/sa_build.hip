@@ -921,7 +921,10 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         // run lengths slide: a block's run lengths read the flags of itself and the next four blocks (exact up to 257),
         // and only the fifth is new in each step - one two-byte load per lane and step instead of ten byte loads.
         const uint32_t nblk = (N + 63) / 64, per = (nblk + SAM_WAVES - 1) / SAM_WAVES;
-        const uint32_t bb = (uint32_t)w * per, be = bb + per < nblk ? bb + per : nblk;
+        // (the wave's index as an SGPR: with bounds the compiler takes for divergent, this loop was compiled with exec
+        // masking, its ballots in VGPRs and its loads waited for where they are issued)
+        const uint32_t wu = (uint32_t)wave_index(tid);
+        const uint32_t bb = wu * per, be = bb + per < nblk ? bb + per : nblk;
         // The loads of a step are issued ahead of their use (4 waves per SIMD hide little latency by themselves, and a
         // step that waited for its flag load and then for the load behind its run took 2.6 us): the flag bytes of a
         // block arrive two steps before their ballot, and the symbols behind the runs of a block are requested
