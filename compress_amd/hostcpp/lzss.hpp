@@ -228,6 +228,50 @@ class Compressor {
     bool noCompression_ = false;
 };
 
+// The reference decoder's message for a stream the device rejected as malformed (lzss/decompress.go:53-55,66-69), from a
+// walk over the phrase boundaries (no bytes are decoded); empty when the stream merely ends inside a phrase.
+// dictLen: length of the augmented dictionary.  The texts are Go's %+v of the reference's backref struct.
+inline std::string DecodeErrorText(const Bytes &data, size_t dictLen) {
+    const size_t total = data.size() * 8;
+    size_t b = size_t(HeaderSize) * 8, outLen = 0;
+    auto bits = [&](size_t pos, int nb) {
+        uint64_t v = 0;
+        for (int k = 0; k < nb; ++k, ++pos) v = (v << 1) | ((data[pos >> 3] >> (7 - (pos & 7))) & 1u);
+        return v;
+    };
+    auto repr = [](long address, long length, int delim, int nbAddr, size_t dl) {
+        const int nb = 8 + nbAddr + 8;
+        return "{address:" + std::to_string(address) + " length:" + std::to_string(length) + " bType:{Delimiter:" +
+               std::to_string(delim) + " NbBitsAddress:" + std::to_string(nbAddr) + " NbBitsLength:8 NbBitsBackRef:" +
+               std::to_string(nb) + " nbBytesBackRef:" + std::to_string((nb + 7) / 8) + " maxAddress:" +
+               std::to_string(1L << nbAddr) + " maxLength:256 DictLen:" + std::to_string(dl) + "}}";
+    };
+    while (b + 8 <= total) {
+        const unsigned s = (unsigned)bits(b, 8);
+        if (s != 0xFE && s != 0xFF) {
+            ++outLen;
+            b += 8;
+            continue;
+        }
+        const int nbAddr = s == 0xFE ? 14 : 21;
+        if (b + 16 + nbAddr > total) return "";
+        const long length = (long)bits(b + 8, 8) + 1, address = (long)bits(b + 16, nbAddr) + 1;
+        if (s == 0xFE) {
+            if (address > (long)outLen)
+                return "invalid short backref " + repr(address, length, 0xFE, 14, 0) + " - output buffer is only " +
+                       std::to_string(outLen) + " bytes long";
+        } else if (address > (long)outLen) {
+            const long dictStart = (long)dictLen - (address - (long)outLen);
+            if (dictStart < 0 || dictStart > (long)dictLen || dictStart + length > (long)dictLen)
+                return "invalid dynamic backref " + repr(address, length, 0xFF, 21, dictLen) + " - dict is only " +
+                       std::to_string(dictLen) + " bytes long; dictStart = " + std::to_string(dictStart);
+        }
+        outLen += (size_t)length;
+        b += 16 + (size_t)nbAddr;
+    }
+    return "";
+}
+
 // lzss/decompress.go:17-84
 inline Bytes Decompress(const Bytes &data, const Bytes &dict, int device = 0, size_t max_out = size_t(1) << 26) {
     Header h;
@@ -250,6 +294,10 @@ inline Bytes Decompress(const Bytes &data, const Bytes &dict, int device = 0, si
     int rc = mi355_lzss_decompress_batch(ctx, data.data(), in_off, 1, out.data(), out_off, &out_len, &status);
     mi355_lzss_ctx_destroy(ctx);
     check(rc);
+    if (status == MI355_LZSS_E_FORMAT) {
+        const std::string msg = DecodeErrorText(data, AugmentDict(dict).size());
+        if (!msg.empty()) throw Error(msg, status);
+    }
     if (status != 0) throw Error("invalid compressed stream", status);
     out.resize(out_len);
     return out;

@@ -411,8 +411,60 @@ def Decompress(data: bytes, dict_: bytes = b"", device: int = 0) -> bytes:
     cap = max(16, (len(data) - HeaderSize) * 8 // 30 * 256 + 512)
     r = decompress_batch(ctx, [data], min(cap, 1 << 28))[0]
     if isinstance(r, LzssError):
+        if r.code == _lib.E_FORMAT:
+            msg = decode_error_text(data, len(AugmentDict(bytes(dict_ or b""))))
+            if msg:
+                raise LzssError(msg, _lib.E_FORMAT)
         raise r
     return r
+
+
+def _backref_repr(address: int, length: int, delimiter: int, nb_addr: int, dict_len: int) -> str:
+    """Go's %+v of the reference's `backref` (lzss/backref.go:21-30,55-59)"""
+    nb = 8 + nb_addr + 8
+    return (f"{{address:{address} length:{length} bType:{{Delimiter:{delimiter} NbBitsAddress:{nb_addr} NbBitsLength:8 "
+            f"NbBitsBackRef:{nb} nbBytesBackRef:{(nb + 7) // 8} maxAddress:{1 << nb_addr} maxLength:256 DictLen:{dict_len}}}}}")
+
+
+def decode_error_text(data: bytes, dict_len: int):
+    """The reference decoder's message for a stream the device rejected as malformed (decompress.go:53-55,66-69).  The
+    device reports MI355_LZSS_E_FORMAT per blob; the text needs the offending phrase, which a walk over the phrase
+    boundaries finds on the host (no bytes are decoded).  None when the stream merely ends inside a phrase (the
+    reference then returns its bit reader's error).  dict_len: length of the AUGMENTED dictionary."""
+    total = len(data) * 8
+    b = HeaderSize * 8
+    out_len = 0
+
+    def bits(pos, nb):
+        v = 0
+        for k in range(nb):
+            q = pos + k
+            v = (v << 1) | ((data[q >> 3] >> (7 - (q & 7))) & 1)
+        return v
+
+    while b + 8 <= total:
+        s = bits(b, 8)
+        if s == 0xFE or s == 0xFF:
+            nb_addr = 14 if s == 0xFE else 21
+            if b + 16 + nb_addr > total:
+                return None
+            length = bits(b + 8, 8) + 1
+            address = bits(b + 16, nb_addr) + 1
+            if s == 0xFE:
+                if address > out_len:
+                    return (f"invalid short backref {_backref_repr(address, length, 0xFE, 14, 0)} - output buffer is only "
+                            f"{out_len} bytes long")
+            elif address > out_len:
+                dict_start = dict_len - (address - out_len)
+                if dict_start < 0 or dict_start > dict_len or dict_start + length > dict_len:
+                    return (f"invalid dynamic backref {_backref_repr(address, length, 0xFF, 21, dict_len)} - dict is only "
+                            f"{dict_len} bytes long; dictStart = {dict_start}")
+            out_len += length
+            b += 16 + nb_addr
+        else:
+            out_len += 1
+            b += 8
+    return None
 
 
 # Decompress builds no index in the reference (decompress.go:34 only augments the dictionary): a decode-only

@@ -346,9 +346,59 @@ func Decompress(data, dict []byte) ([]byte, error) {
 		return nil, lastError(rc)
 	}
 	if status != 0 {
+		if status == C.MI355_LZSS_E_FORMAT {
+			if err := decodeError(data, len(AugmentDict(dict))); err != nil {
+				return nil, err
+			}
+		}
 		return nil, fmt.Errorf("invalid compressed stream (status %d)", int(status))
 	}
 	return out[:outLen], nil
+}
+
+// decodeError rebuilds the reference decoder's message for a stream the device rejected as malformed
+// (lzss/decompress.go:53-55,66-69): a walk over the phrase boundaries finds the offending phrase (no bytes are
+// decoded).  nil when the stream merely ends inside a phrase.  dictLen: length of the augmented dictionary.
+func decodeError(data []byte, dictLen int) error {
+	r := bitWalker{data: data, pos: HeaderSize * 8}
+	total := len(data) * 8
+	outLen := 0
+	for r.pos+8 <= total {
+		s := byte(r.read(8))
+		if s != SymbolShort && s != SymbolDynamic {
+			outLen++
+			continue
+		}
+		nbAddr := 14
+		if s == SymbolDynamic {
+			nbAddr = 21
+		}
+		if r.pos+8+nbAddr > total {
+			return nil
+		}
+		b := backref{length: int(r.read(8)) + 1, address: int(r.read(nbAddr)) + 1}
+		if s == SymbolShort {
+			b.bType = NewShortBackrefType()
+			if b.address > outLen {
+				return fmt.Errorf("invalid short backref %+v - output buffer is only %d bytes long", b, outLen)
+			}
+		} else if b.address > outLen {
+			b.bType = NewDynamicBackrefType(dictLen, outLen)
+			dictStart := dictLen - (b.address - outLen)
+			if dictStart < 0 || dictStart > dictLen || dictStart+b.length > dictLen {
+				return fmt.Errorf("invalid dynamic backref %+v - dict is only %d bytes long; dictStart = %d", b, dictLen, dictStart)
+			}
+		}
+		outLen += b.length
+	}
+	return nil
+}
+
+// backref: lzss/backref.go:55-59 (here only for the %+v of the decoder's messages)
+type backref struct {
+	address int
+	length  int
+	bType   BackrefType
 }
 
 // CompressBatch compresses independent blobs that share c's dictionary in one device launch
