@@ -629,7 +629,10 @@ __device__ inline int wave_incl_min(int v, int lane) {
 // One lane per rank.  The walks to the nearest in-window neighbours are short for most ranks and very long
 // for a few (heavy tail), so a lane walks SCAN_CAP x 4 ranks alone; whatever is left is finished by the
 // whole wave, 64 ranks per step (coalesced loads, prefix-min of LCP across lanes, ballot for the first hit).
-__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, BatchIndex ix,
+#ifndef MATCH_WAVES_PER_EU
+#define MATCH_WAVES_PER_EU 8
+#endif
+__global__ __launch_bounds__(MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(MATCH_WAVES_PER_EU, MATCH_WAVES_PER_EU))) void match_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, BatchIndex ix,
                                                               DictView D, const int32_t *dlb, uint32_t *res, int skip_unqueried, int defer,
                                                               int ablate) {
     const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);
