@@ -338,12 +338,17 @@ __device__ inline void image_put(uint32_t *w, uint32_t o, uint64_t v, int nb) {
     if (w2) atomicOr(&w[wi + 2], w2);
 }
 
-__global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, const uint8_t *text,
+#ifndef EMIT_WAVES_PER_EU
+#define EMIT_WAVES_PER_EU 7   // (8 costs 112 spilled SGPRs for nothing: 11.87 vs 11.84 ms)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMIT_WAVES_PER_EU, EMIT_WAVES_PER_EU))) void emit_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, const uint8_t *text,
                                                   const uint32_t *res, BatchIndex ix, DictView D, WalkWork ww, uint32_t header_bytes,
                                                   uint32_t bit_off, uint32_t dict_len, int32_t res_idx_fe, int32_t res_idx_ff,
                                                   uint8_t *out_buf, uint64_t out_cap, int32_t *status, int split) {
-    __shared__ uint32_t s_kind32[64], s_adv32[64], s_text32[65], s_res[TILE], s_out[EMIT_WORDS];
-    __shared__ uint16_t s_jump[7][TILE + 2];
+    // 5.1 KB of LDS per wave, so that eight waves per SIMD fit a CU's 160 KB (with the match results staged as well and a
+    // seventh jump level it was 6.6 KB: six waves)
+    __shared__ uint32_t s_kind32[64], s_adv32[64], s_text32[65], s_out[EMIT_WORDS];
+    __shared__ uint16_t s_jump[6][TILE + 2];
     const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);
     if (vb >= gx * n_segs) return;
     const uint32_t si = vb / gx;
@@ -378,10 +383,9 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
     s_adv32[lane] = reinterpret_cast<const uint32_t *>(ww.adv + gbase)[lane];
     s_text32[lane] = reinterpret_cast<const uint32_t *>(text + gbase)[lane];
     if (lane == 0) s_text32[64] = (t + 1 < ntiles) ? text[gbase + TILE] : 0u;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s_res[lane + 64 * q] = res[gbase + lane + 64 * q];
+    const uint32_t *tres = res + gbase;  // the match results of the tile's phrases are read where they lie (a few per lane)
     for (int j = lane; j < EMIT_WORDS; j += 64) s_out[j] = 0;
-    if (lane < 7) s_jump[lane][TILE] = TILE;
+    if (lane < 6) s_jump[lane][TILE] = TILE;
     __syncthreads();
     const uint8_t *s_kind = (const uint8_t *)s_kind32, *s_adv = (const uint8_t *)s_adv32, *s_text = (const uint8_t *)s_text32;
 #pragma unroll
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
         s_jump[0][x] = (uint16_t)((x < hi && nx < hi) ? nx : TILE);
     }
     __syncthreads();
-    for (int k = 1; k < 7; ++k) {
+    for (int k = 1; k < 6; ++k) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int x = lane + 64 * q;
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             xs[j] = x;
-            x = s_jump[6][x];
+            x = s_jump[5][s_jump[5][x]];  // 64 phrases on
         }
     }
     const uint32_t lead = (uint32_t)(b0 & 7);
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
             case K_LIT: v1 = s_text[x]; n1 = 8; break;
             case K_LIT2: v1 = ((uint64_t)s_text[x] << 8) | s_text[x + 1]; n1 = 16; break;
             case K_SHORT: {
-                const uint32_t r = s_res[x];
+                const uint32_t r = tres[x];
                 uint32_t f = res_field(r);
                 if (res_pending(r)) {
                     if (split) { f = 0; later = true; }
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(64) void emit_kernel(const Seg *segs, uint32_t n_se
                 break;
             }
             case K_DYN: {
-                const uint32_t r = s_res[x];
+                const uint32_t r = tres[x];
                 uint32_t f = res_field(r);
                 if (res_type(r) == RES_DICT || res_pending(r)) {
                     if (split) { f = 0; later = true; }
