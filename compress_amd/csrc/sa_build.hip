@@ -1258,6 +1258,13 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
 // the suffix array: the window meets at most two chunks, and inside a chunk the condition is one-sided.
 constexpr int WIN_SHIFT = LZSS_SHORT_ADDR_BITS;  // chunk = 2^14 positions
 
+// lanes of `amask` whose chunk number equals this lane's: unrolled for the common widths (8 chunks = texts of 128 KiB)
+__device__ inline uint64_t chunk_peers(int c, uint64_t amask, int cbits) {
+    if (cbits <= 3) return match_bits<3>(c, amask);
+    if (cbits <= 5) return match_bits<5>(c, amask);
+    return match_digit_n(c, amask, cbits);
+}
+
 __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *segs, BatchIndex ix) {
     __shared__ SaShared sh;
     const Seg sg = segs[blockIdx.x];
@@ -1283,7 +1290,7 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
         const bool active = k < cend;
         const int c = active ? (sa_next >> WIN_SHIFT) : 0;
         sa_next = k + 64 < cend ? SA[k + 64] : 0;
-        const uint64_t peers = match_digit_n(c, __ballot(active), cbits);
+        const uint64_t peers = chunk_peers(c, __ballot(active), cbits);
         if (active && (peers & lanemask_lt(lane)) == 0) sh.hist[w][c] += __popcll(peers);
     }
     __syncthreads();
@@ -1309,7 +1316,7 @@ __global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *seg
         for (int cc = lane; cc < nch; cc += 64) cdir[((k0 - 1) >> 6) * ix.nch + cc] = (uint16_t)(hrow[cc] - (cc << WIN_SHIFT));
         __builtin_amdgcn_wave_barrier();
         const uint64_t amask = __ballot(active);
-        const uint64_t peers = match_digit_n(c, amask, cbits);
+        const uint64_t peers = chunk_peers(c, amask, cbits);
         const int cnt = __popcll(peers);
         const int rank = __popcll(peers & lanemask_lt(lane));
         const int base = hrow[c];
