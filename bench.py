@@ -133,9 +133,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # MI355_BENCH_REHEARSE=1: the N > 1 launch path on a box with fewer GPUs than ranks (ranks share the devices, gloo
+    # carries the barrier and the reductions) - for checking the multi-process flow, never for a number
+    rehearse = os.environ.get("MI355_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if rehearse else "cuda"
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import compress_amd
     from compress_amd import batch as B
@@ -164,7 +173,7 @@ def main():
         bt.compress()                      # returns after the library's stream has drained
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, device="cuda")
+    elapsed = shard.max_over_ranks(elapsed, device=red_dev)
     stage_sum = {}
     ctx.set_overlap(1)
     for _ in range(args.stage_steps):
@@ -189,7 +198,7 @@ def main():
         dec_ms += bt.stage_times()["decompress"]
     barrier()
     dec_elapsed = time.perf_counter() - t0
-    dec_elapsed = shard.max_over_ranks(dec_elapsed, device="cuda")
+    dec_elapsed = shard.max_over_ranks(dec_elapsed, device=red_dev)
     back = bt.download_decompressed()
     dec_ok = back == blobs
 
@@ -229,7 +238,7 @@ def main():
         t0 = time.perf_counter()
         run_pipe()
         barrier()
-        t_pipe = shard.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        t_pipe = shard.max_over_ranks(time.perf_counter() - t0, device=red_dev)
         same = all(pin_out.array[int(out_off[k]):int(out_off[k]) + int(p_len[k])].tobytes() == outs[k % len(blobs)]
                    for k in range(0, nb, max(1, nb // 97)))
         pipe = {"value": round(in_bytes * reps * world / t_pipe / 1e6, 2), "unit": "MB/s", "blobs_per_gpu": nb,
