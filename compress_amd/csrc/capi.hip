@@ -113,6 +113,10 @@ struct mi355_lzss_ctx {
     static constexpr int kMaxSplit = 4;
     hipStream_t side[kMaxSplit] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kMaxSplit] = {};
+    // per part: the head positions' brute-force search and the dictionary brackets (no LDS, few registers) run on a stream
+    // of their own beside the LCP kernel, which fills a CU's LDS with half of its wave slots
+    hipStream_t aux[kMaxSplit] = {};
+    hipEvent_t sa_ev[kMaxSplit] = {}, head_ev[kMaxSplit] = {};
     int split = 2;
     // workspaces of the entry points that may be called concurrently (compressed_size: compress.go:381-383)
     std::mutex pool_mu;
@@ -428,6 +432,11 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
         if (!ctx->side[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
         if (!ctx->join_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->join_ev[k], hipEventDisableTiming));
     }
+    for (int k = 0; k < split; ++k) {
+        if (!ctx->aux[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking));
+        if (!ctx->sa_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->sa_ev[k], hipEventDisableTiming));
+        if (!ctx->head_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->head_ev[k], hipEventDisableTiming));
+    }
     if ((rc = mark(b, ST_SA)) != 0) return rc;
     HIP_TRY(hipEventRecord(ctx->fork_ev, sm));
     for (int k = 0; k < split; ++k) {
@@ -437,9 +446,13 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
         const uint32_t cnt = hi - lo;
         if (k) HIP_TRY(hipStreamWaitEvent(st, ctx->fork_ev, 0));
         HIP_TRY((hipError_t)launch_sa_build(sg, b->h_segs.data() + lo, cnt, b->max_n, b->text.as<uint8_t>(), sa_work(b), st));
+        HIP_TRY(hipEventRecord(ctx->sa_ev[k], st));
+        HIP_TRY(hipStreamWaitEvent(ctx->aux[k], ctx->sa_ev[k], 0));
+        launch_match_head(sg, cnt, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), ctx->aux[k]);
+        HIP_TRY(hipEventRecord(ctx->head_ev[k], ctx->aux[k]));
         launch_lcp(sg, cnt, b->max_n, batch_index(b), st);
         launch_window_index(sg, cnt, b->max_n, batch_index(b), st);
-        launch_match_head(sg, cnt, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), st);
+        HIP_TRY(hipStreamWaitEvent(st, ctx->head_ev[k], 0));
         launch_match(sg, cnt, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), skip_unqueried, st);
         if (k) HIP_TRY(hipEventRecord(ctx->join_ev[k], st));
     }
@@ -879,6 +892,9 @@ extern "C" void mi355_lzss_ctx_destroy(mi355_lzss_ctx *ctx) {
     for (int k = 0; k < mi355_lzss_ctx::kMaxSplit; ++k) {
         if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
         if (ctx->join_ev[k]) (void)hipEventDestroy(ctx->join_ev[k]);
+        if (ctx->aux[k]) (void)hipStreamDestroy(ctx->aux[k]);
+        if (ctx->sa_ev[k]) (void)hipEventDestroy(ctx->sa_ev[k]);
+        if (ctx->head_ev[k]) (void)hipEventDestroy(ctx->head_ev[k]);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
