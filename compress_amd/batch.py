@@ -39,6 +39,13 @@ class Batch:
         self.n_blobs = len(blobs)
         self.lens = [len(b) for b in blobs]
 
+    def upload_flat(self, flat: np.ndarray, off: np.ndarray):
+        """upload() for blobs that already lie back to back: `flat` uint8, `off` uint64 CSR offsets (no host copies)"""
+        n = off.size - 1
+        _check(_lib.lib().mi355_lzss_batch_upload(self.h, _ptr(flat) if flat.size else None, _ptr(off), n, None))
+        self.n_blobs = n
+        self.lens = [int(x) for x in np.diff(off.astype(np.int64))]
+
     def compress(self, with_header: bool = True):
         _check(_lib.lib().mi355_lzss_batch_compress(self.h, 1 if with_header else 0))
 

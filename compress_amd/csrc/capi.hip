@@ -998,7 +998,22 @@ static int pool_acquire(mi355_lzss_ctx *ctx, mi355_lzss_batch **out) {
     *out = b;
     return 0;
 }
+// a pooled workspace keeps what it grew to (~40 B per element); one that a single large call blew up beyond this many
+// elements (~13 GB) is given back to the device when it returns to the pool instead of staying until ctx_destroy
+constexpr uint64_t POOL_KEEP_ELEMS = 320ull << 20;
 static void pool_release(mi355_lzss_ctx *ctx, mi355_lzss_batch *b) {
+    if (b->cap_elems > POOL_KEEP_ELEMS) {
+        {
+            std::lock_guard<std::mutex> lk(ctx->pool_mu);
+            for (size_t k = 0; k < ctx->pool_all.size(); ++k)
+                if (ctx->pool_all[k] == b) {
+                    ctx->pool_all.erase(ctx->pool_all.begin() + (long)k);
+                    break;
+                }
+        }
+        mi355_lzss_batch_destroy(b);
+        return;
+    }
     std::lock_guard<std::mutex> lk(ctx->pool_mu);
     ctx->pool_free.push_back(b);
 }
@@ -1057,6 +1072,8 @@ static void append_bits(std::vector<uint8_t> &dst, uint64_t &pos, const uint8_t 
     pos += nbits;
 }
 
+constexpr uint64_t PACK_BATCH_BYTES = 256ull << 20;  // candidate prefixes of one mi355_lzss_pack_blob batch (~10 GB of workspace)
+
 extern "C" int mi355_lzss_pack_blob(mi355_lzss_ctx *ctx, const uint8_t *data, uint64_t n, uint32_t chunk, uint64_t out_max,
                                     uint32_t lookahead, uint8_t *out, uint64_t out_cap, uint64_t *out_len, uint64_t *chunks,
                                     int *needs_loop) {
@@ -1103,11 +1120,17 @@ extern "C" int mi355_lzss_pack_blob(mi355_lzss_ctx *ctx, const uint8_t *data, ui
             off.clear();
             plen.clear();
             starts.clear();
+            // a candidate is a whole prefix of the stream's rest and costs ~40 B of workspace per position: the batch is
+            // bounded by the SUM of the prefix lengths too (small chunks with a large out_max would otherwise reserve
+            // tens of GB), at least one candidate per batch
+            uint64_t sum_len = 0;
             for (uint64_t t = 0; t < look; ++t) {
                 const uint64_t s = (j + t) * (uint64_t)chunk;
                 if (s >= n) break;
                 const uint64_t e = std::min<uint64_t>(s + chunk, n);
                 if (e > LZSS_MAX_INPUT_SIZE) break;  // Write would fail there (compress.go:473); the loop ends before it
+                if (t > 0 && sum_len + e > PACK_BATCH_BYTES) break;
+                sum_len += e;
                 off.push_back(0);  // every candidate's inBuf is a prefix of the stream's rest: the bytes go up once
                 plen.push_back(e);
                 starts.push_back((uint32_t)s);
@@ -1247,20 +1270,35 @@ static int compress_pipelined(mi355_lzss_ctx *ctx, const uint8_t *in, const uint
         if (w && !worst) worst = w;
         return 0;
     };
-    for (size_t k = 0; k < chunks.size(); ++k) {
-        const int s = (int)(k & 1);
-        mi355_lzss_batch *b = p->slot[s];
-        const Chunk &c = chunks[k];
-        // slot s is free: chunk k-2 was finished (synchronised) in the previous iteration
-        if ((rc = upload_async(b, in, in_off + c.first, c.last - c.first, nullptr, LZSS_MAX_INPUT_SIZE, p->s_in)) != 0) return rc;
-        HIP_TRY(hipEventRecord(p->ev_up[s], p->s_in));
-        HIP_TRY(hipStreamWaitEvent(ctx->stream, p->ev_up[s], 0));
-        if ((rc = run_index_and_match(b, true)) != 0) return rc;
-        if ((rc = enqueue_walk_emit(b, LZSS_HEADER_SIZE, 0, true)) != 0) return rc;
-        HIP_TRY(hipEventRecord(p->ev_done[s], ctx->stream));
-        if (k >= 1 && (rc = finish(k - 1)) != 0) return rc;
+    auto run = [&]() -> int {
+        int r;
+        for (size_t k = 0; k < chunks.size(); ++k) {
+            const int s = (int)(k & 1);
+            mi355_lzss_batch *b = p->slot[s];
+            const Chunk &c = chunks[k];
+            // slot s is free: chunk k-2 was finished (synchronised) in the previous iteration
+            if ((r = upload_async(b, in, in_off + c.first, c.last - c.first, nullptr, LZSS_MAX_INPUT_SIZE, p->s_in)) != 0) return r;
+            HIP_TRY(hipEventRecord(p->ev_up[s], p->s_in));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, p->ev_up[s], 0));
+            if ((r = run_index_and_match(b, true)) != 0) return r;
+            if ((r = enqueue_walk_emit(b, LZSS_HEADER_SIZE, 0, true)) != 0) return r;
+            HIP_TRY(hipEventRecord(p->ev_done[s], ctx->stream));
+            if (k >= 1 && (r = finish(k - 1)) != 0) return r;
+        }
+        if (!chunks.empty() && (r = finish(chunks.size() - 1)) != 0) return r;
+        return 0;
+    };
+    rc = run();
+    if (rc != 0) {
+        // an error exit leaves copies that read the caller's `in`, kernels of one or two chunks and possibly a download
+        // in flight: drain all three streams (and the side streams the kernels fork onto, which join ctx->stream) before
+        // the caller may release its buffers or the next call reuses the two slots.  The first error is the one reported.
+        (void)hipStreamSynchronize(p->s_in);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(p->s_out);
+        (void)hipDeviceSynchronize();
+        return rc;
     }
-    if (!chunks.empty() && (rc = finish(chunks.size() - 1)) != 0) return rc;
     if (worst && !status) return fail(worst, "blob failed with status %d", worst);
     return 0;
 }

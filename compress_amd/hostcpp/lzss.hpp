@@ -229,7 +229,7 @@ class Compressor {
 };
 
 // The reference decoder's message for a stream the device rejected as malformed (lzss/decompress.go:53-55,66-69), from a
-// walk over the phrase boundaries (no bytes are decoded); empty when the stream merely ends inside a phrase.
+// walk over the phrase boundaries (no bytes are decoded); "EOF" when the stream ends inside a phrase.
 // dictLen: length of the augmented dictionary.  The texts are Go's %+v of the reference's backref struct.
 inline std::string DecodeErrorText(const Bytes &data, size_t dictLen) {
     const size_t total = data.size() * 8;
@@ -254,7 +254,7 @@ inline std::string DecodeErrorText(const Bytes &data, size_t dictLen) {
             continue;
         }
         const int nbAddr = s == 0xFE ? 14 : 21;
-        if (b + 16 + nbAddr > total) return "";
+        if (b + 16 + nbAddr > total) return "EOF";  // readFrom returns the bit reader's io.EOF (backref.go:77-79)
         const long length = (long)bits(b + 8, 8) + 1, address = (long)bits(b + 16, nbAddr) + 1;
         if (s == 0xFE) {
             if (address > (long)outLen)

@@ -6,6 +6,7 @@ Write run on the GPU (mi355_lzss_write), the few bytes of stream state (header, 
 Revert bookkeeping) stay here exactly as in compress.go:91-129,289-367.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -407,9 +408,14 @@ def Decompress(data: bytes, dict_: bytes = b"", device: int = 0) -> bytes:
         raise LzssError("unsupported compressor version")
     if h.NoCompression:
         return data[HeaderSize:]
-    ctx = _decoder_ctx(bytes(dict_ or b""), device)
     cap = max(16, (len(data) - HeaderSize) * 8 // 30 * 256 + 512)
-    r = decompress_batch(ctx, [data], min(cap, 1 << 28))[0]
+    while True:
+        ent = _decoder_entry(bytes(dict_ or b""), device)
+        with ent.lock:
+            if ent.ctx is None:   # evicted between the lookup and the lock: fetch (or rebuild) it again
+                continue
+            r = decompress_batch(ent.ctx, [data], min(cap, 1 << 28))[0]
+        break
     if isinstance(r, LzssError):
         if r.code == _lib.E_FORMAT:
             msg = decode_error_text(data, len(AugmentDict(bytes(dict_ or b""))))
@@ -429,8 +435,9 @@ def _backref_repr(address: int, length: int, delimiter: int, nb_addr: int, dict_
 def decode_error_text(data: bytes, dict_len: int):
     """The reference decoder's message for a stream the device rejected as malformed (decompress.go:53-55,66-69).  The
     device reports MI355_LZSS_E_FORMAT per blob; the text needs the offending phrase, which a walk over the phrase
-    boundaries finds on the host (no bytes are decoded).  None when the stream merely ends inside a phrase (the
-    reference then returns its bit reader's error).  dict_len: length of the AUGMENTED dictionary."""
+    boundaries finds on the host (no bytes are decoded).  A stream that ends inside a phrase gives "EOF": readFrom returns
+    the bit reader's TryError (backref.go:77-79), and bitio hands on the io.EOF of the bytes.Reader under it.  None for a
+    stream without an offending phrase.  dict_len: length of the AUGMENTED dictionary."""
     total = len(data) * 8
     b = HeaderSize * 8
     out_len = 0
@@ -447,7 +454,7 @@ def decode_error_text(data: bytes, dict_len: int):
         if s == 0xFE or s == 0xFF:
             nb_addr = 14 if s == 0xFE else 21
             if b + 16 + nb_addr > total:
-                return None
+                return "EOF"
             length = bits(b + 8, 8) + 1
             address = bits(b + 16, nb_addr) + 1
             if s == 0xFE:
@@ -469,18 +476,33 @@ def decode_error_text(data: bytes, dict_len: int):
 
 # Decompress builds no index in the reference (decompress.go:34 only augments the dictionary): a decode-only
 # context per (dictionary, device), kept in a small LRU so that a caller that decompresses in a loop pays the
-# dictionary upload once
+# dictionary upload once.  A context is not thread-safe (its batch scratch is shared) and the reference's Decompress
+# is a pure function, so every cache entry carries a lock that Decompress holds across its device call; the cache
+# itself is guarded by _DECODERS_LOCK, and an evicted context is closed only once its lock is free.
 _DECODERS = {}
 _DECODERS_MAX = 4
+_DECODERS_LOCK = threading.Lock()
 
 
-def _decoder_ctx(dict_: bytes, device: int):
+class _Decoder:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lock = threading.Lock()
+
+
+def _decoder_entry(dict_: bytes, device: int) -> _Decoder:
     import hashlib
     key = (hashlib.sha256(dict_).digest(), len(dict_), device)
-    ctx = _DECODERS.pop(key, None)
-    if ctx is None:
-        ctx = _Ctx(dict_, device, decoder=True)
-        while len(_DECODERS) >= _DECODERS_MAX:
-            _DECODERS.pop(next(iter(_DECODERS))).close()
-    _DECODERS[key] = ctx   # most recently used last
-    return ctx
+    evicted = []
+    with _DECODERS_LOCK:
+        ent = _DECODERS.pop(key, None)
+        if ent is None:
+            ent = _Decoder(_Ctx(dict_, device, decoder=True))
+            while len(_DECODERS) >= _DECODERS_MAX:
+                evicted.append(_DECODERS.pop(next(iter(_DECODERS))))
+        _DECODERS[key] = ent   # most recently used last
+    for old in evicted:        # outside the cache lock: waits for a Decompress that still uses the context
+        with old.lock:
+            old.ctx.close()
+            old.ctx = None
+    return ent

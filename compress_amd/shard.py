@@ -13,6 +13,12 @@ def shard_ids(rank: int, world: int, blobs_per_rank: int):
     return [rank + world * k for k in range(blobs_per_rank)]
 
 
+def batch_shard_ids(rank: int, world: int, total: int):
+    """This rank's blobs of ONE batch of `total` blobs sharded per blob (config 3 as stated: 10 000 blobs over the
+    node's GPUs, strong scaling): ids b < total with b mod world == rank - a prefix of shard_ids(rank, world, total)."""
+    return list(range(rank, total, world))
+
+
 def owner(blob_id: int, world: int) -> int:
     return blob_id % world
 

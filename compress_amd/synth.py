@@ -121,3 +121,35 @@ def dictionary(size: int = DICT_SIZE) -> bytes:
 
 def blobs(first: int, count: int, size: int = BLOB_SIZE):
     return [blob(first + k, size) for k in range(count)]
+
+
+def blobs_array(first: int, stride: int, count: int, size: int = BLOB_SIZE, threads: int = 8) -> np.ndarray:
+    """Blobs first, first + stride, ... as ONE (count, size) uint8 array, from the C twin of this generator
+    (compress_amd/synth_fast.c -> libsynth_fast.so, built by compress_amd/csrc/Makefile; ~0.6 ms per blob and no forked
+    workers, which bench.py must not start under rocprofv3).  Byte for byte blob(): tests/test_synth_fast.py."""
+    import ctypes
+    import os
+    import threading
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsynth_fast.so")
+    if not os.path.exists(path):
+        raise ImportError(path + " is missing: build it with `make -C compress_amd/csrc`")
+    lib = ctypes.CDLL(path)
+    lib.synth_fast_blobs.argtypes = [ctypes.c_uint64] * 4 + [ctypes.c_void_p]
+    lib.synth_fast_blobs.restype = None
+    out = np.empty((count, size), dtype=np.uint8)
+    if count == 0:
+        return out
+    lib.synth_fast_blobs(first, stride, 1, size, out.ctypes.data)  # also fills the pools once, before the threads
+    threads = max(1, min(threads, count - 1))
+    per = (count - 1 + threads - 1) // threads if count > 1 else 0
+
+    def work(t):
+        lo, hi = 1 + t * per, min(count, 1 + (t + 1) * per)
+        if lo < hi:
+            lib.synth_fast_blobs(first + stride * lo, stride, hi - lo, size, out[lo].ctypes.data)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(threads)] if count > 1 else []
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    return out

@@ -329,11 +329,19 @@ func Decompress(data, dict []byte) ([]byte, error) {
 	if data[2] == 1 {
 		return data[HeaderSize:], nil
 	}
-	dec, err := decoder(dict)
-	if err != nil {
-		return nil, err
+	var dec *decoderCtx
+	for {
+		d, err := decoder(dict)
+		if err != nil {
+			return nil, err
+		}
+		d.mu.Lock() // a ctx is not goroutine-safe
+		if d.ctx != nil {
+			dec = d
+			break
+		}
+		d.mu.Unlock() // evicted (destroyed) between the cache lookup and the lock: fetch or rebuild it
 	}
-	dec.mu.Lock() // a ctx is not goroutine-safe
 	defer dec.mu.Unlock()
 	ctx := dec.ctx
 	capOut := (len(data)-HeaderSize)*8/30*256 + 512
@@ -358,7 +366,7 @@ func Decompress(data, dict []byte) ([]byte, error) {
 
 // decodeError rebuilds the reference decoder's message for a stream the device rejected as malformed
 // (lzss/decompress.go:53-55,66-69): a walk over the phrase boundaries finds the offending phrase (no bytes are
-// decoded).  nil when the stream merely ends inside a phrase.  dictLen: length of the augmented dictionary.
+// decoded).  io.EOF when the stream ends inside a phrase.  dictLen: length of the augmented dictionary.
 func decodeError(data []byte, dictLen int) error {
 	r := bitWalker{data: data, pos: HeaderSize * 8}
 	total := len(data) * 8
@@ -374,7 +382,7 @@ func decodeError(data []byte, dictLen int) error {
 			nbAddr = 21
 		}
 		if r.pos+8+nbAddr > total {
-			return nil
+			return io.EOF // readFrom returns the bit reader's TryError (backref.go:77-79)
 		}
 		b := backref{length: int(r.read(8)) + 1, address: int(r.read(nbAddr)) + 1}
 		if s == SymbolShort {

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 name=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$name
 rm -rf $out
-timeout -s KILL 150 rocprofv3 --pmc $1 -d $out -o pmc --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-repeats 0 > $out.log 2>&1
+timeout -s KILL 150 rocprofv3 --pmc $1 -d $out -o pmc --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-steps 0 > $out.log 2>&1
 python3 - "$out" <<'PY'
 import sys,csv,glob,collections
 f=glob.glob(sys.argv[1]+'/**/*counter_collection.csv',recursive=True)

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 $root/bench.py --steps 5 --warmup 1 > $out/${tag}_bench.log 2>&1 || { echo "bench failed"; tail -5 $out/${tag}_bench.log; exit 1; }
 tail -1 $out/${tag}_bench.log > $out/${tag}_bench.json
 rm -rf $out/${tag}_trace
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o t --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-repeats 0 > $out/${tag}_trace.log 2>&1 || { echo "trace failed"; exit 1; }
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o t --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-steps 0 > $out/${tag}_trace.log 2>&1 || { echo "trace failed"; exit 1; }
 cp $(find $out/${tag}_trace -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 # the same statistics over the launches of the whole batch only (rocprofv3's own summary also averages in the
 # one-segment launches that index the dictionary at context creation)
@@ -30,7 +30,7 @@ with open(sys.argv[2],"w") as f:
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $out/${tag}_pmc_$c
-  timeout -s KILL 200 rocprofv3 --pmc $c -d $out/${tag}_pmc_$c -o p --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-repeats 0 > $out/${tag}_pmc_$c.log 2>&1 || { echo "pmc $c failed"; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc $c -d $out/${tag}_pmc_$c -o p --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-steps 0 > $out/${tag}_pmc_$c.log 2>&1 || { echo "pmc $c failed"; exit 1; }
 done
 python3 - "$out" "$tag" <<'PY'
 import sys,csv,glob,collections,re

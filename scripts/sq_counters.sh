@@ -23,7 +23,7 @@ failed=0
 for grp in "${groups[@]:$g}"; do
   echo "[sq_counters] group $g: $grp"
   rm -rf $out/${tag}_sq_$g
-  timeout -s KILL 300 rocprofv3 --pmc $grp -d $out/${tag}_sq_$g -o p --output-format csv -- python3 $root/bench.py --blobs $blobs --steps 1 --warmup 1 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-repeats 0 > $out/${tag}_sq_$g.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc $grp -d $out/${tag}_sq_$g -o p --output-format csv -- python3 $root/bench.py --blobs $blobs --steps 1 --warmup 1 --overlap 1 --stage-steps 1 --no-cpu --no-stream --no-latency --pipe-steps 0 > $out/${tag}_sq_$g.log 2>&1
   rc=$?
   # (after a kill nothing more is started on the GPU in this call; the summary below is host work)
   if [ $rc -ne 0 ]; then echo "group $g ($grp) failed rc=$rc"; tail -3 $out/${tag}_sq_$g.log; if [ $rc -ge 124 ]; then failed=1; break; fi; fi

@@ -101,3 +101,72 @@ def test_partition_is_host_only_and_balanced():
     # equal blobs: equal shares (config 3: 10 000 blobs over 8 GPUs = 1250 each)
     off = (np.arange(10001, dtype=np.uint64) * 131072)
     assert compress_amd.partition(off, 8) == [1250 * t for t in range(9)]
+
+
+# ---- the Go shim cannot be compiled in this image (no Go toolchain); two mechanical checks stand in for the compiler
+
+def test_header_compiles_as_c99():
+    """cgo hands include/mi355_lzss.h to a C compiler: it must be plain C (no C++-isms), warning-free"""
+    src = '#include "mi355_lzss.h"\nint main(void) { return (int)sizeof(mi355_lzss_ctx *) > 0 ? 0 : 1; }\n'
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c",
+                        "-I", os.path.join(ROOT, "include"), "-"], input=src, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def header_prototypes():
+    """name -> number of parameters, from the declarations of include/mi355_lzss.h"""
+    text = open(os.path.join(ROOT, "include", "mi355_lzss.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    protos = {}
+    for m in re.finditer(r"\b(mi355_lzss_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(split_args(args))
+    return protos
+
+
+def split_args(s):
+    """top-level comma split of an argument list"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def go_calls():
+    """(name, argument count, line) of every C.mi355_lzss_*( call in go/lzss/lzss.go"""
+    text = open(os.path.join(ROOT, "go", "lzss", "lzss.go")).read()
+    calls = []
+    for m in re.finditer(r"\bC\.(mi355_lzss_[a-z0-9_]+)\(", text):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        args = text[m.end():i - 1].strip()
+        calls.append((m.group(1), len(split_args(args)) if args else 0, text.count("\n", 0, m.start()) + 1))
+    return calls
+
+
+def test_go_shim_calls_match_the_header():
+    protos = header_prototypes()
+    assert sorted(protos) == declared_symbols()
+    calls = go_calls()
+    assert len(calls) >= 10
+    for name, nargs, line in calls:
+        assert name in protos, f"go/lzss/lzss.go:{line}: {name} is not declared in include/mi355_lzss.h"
+        assert nargs == protos[name], f"go/lzss/lzss.go:{line}: {name} called with {nargs} arguments, declared with {protos[name]}"
+    # constants the shim takes from the header
+    text = open(os.path.join(ROOT, "go", "lzss", "lzss.go")).read()
+    hdr = open(os.path.join(ROOT, "include", "mi355_lzss.h")).read()
+    for c in set(re.findall(r"\bC\.(MI355_LZSS_[A-Z0-9_]+)\b", text)):
+        assert re.search(r"\b%s\b" % c, hdr), c

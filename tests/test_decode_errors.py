@@ -26,7 +26,7 @@ def test_messages_from_the_phrase_walk():
     short, dyn = streams()
     assert lzss.decode_error_text(short, 0) == SHORT_MSG
     assert lzss.decode_error_text(dyn, len(lzss.AugmentDict(b"abcdef"))) == DYN_MSG
-    assert lzss.decode_error_text(bytes.fromhex("00010001fe04"), 0) is None          # truncated: the bit reader's error
+    assert lzss.decode_error_text(bytes.fromhex("00010001fe04"), 0) == "EOF"         # truncated: the bit reader's io.EOF
     assert lzss.decode_error_text(bytes.fromhex("00010001fe040000"), 0) is None      # a valid stream
     # literals count towards the output length: one literal in front, address 2 > 1
     bits = (0xFE << 22) | (0 << 14) | 1
@@ -44,3 +44,13 @@ def test_decompress_raises_the_reference_texts():
     with pytest.raises(amd.LzssError) as e:
         amd.Decompress(dyn, b"abcdef")
     assert str(e.value) == DYN_MSG
+
+
+@pytest.mark.gpu
+def test_truncated_reference_raises_the_readers_eof():
+    """a stream that ends inside a back-reference: readFrom returns the bit reader's TryError (backref.go:77-79), io.EOF"""
+    import compress_amd as amd
+    for s in ("00010001fe04", "00010001ff0400", "000100fe"):
+        with pytest.raises(amd.LzssError) as e:
+            amd.Decompress(bytes.fromhex(s), b"")
+        assert str(e.value) == "EOF"

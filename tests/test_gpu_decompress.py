@@ -109,3 +109,37 @@ def test_streaming_blobs_decode_on_gpu(amd, dict_naive, average_block):
         i0 = i
     got = amd.decompress_batch(gc, streams, 20000)
     assert got == spans
+
+
+@pytest.mark.gpu
+def test_decompress_from_several_threads_with_one_dictionary(dict_naive):
+    """Decompress is a pure function in the reference (decompress.go:17-84); here its decode-only context comes from a
+    cache, so threads that share a dictionary share a context and must take turns on it, and more dictionaries than the
+    cache holds make it evict (and close) contexts while other threads decompress"""
+    import threading
+    import compress_amd as amd
+    from compress_amd import synth
+    comp = amd.Compressor(dict_naive, device=0)
+    datas = [synth.blob(k, 20000 + 977 * k) for k in range(6)]
+    streams = [comp.Compress(d) for d in datas]
+    dicts = [bytes([k]) * (k + 1) for k in range(7)]     # > the cache's 4 entries
+    small = [(amd.Compressor(dk, device=0).Compress(b"abcabcabc" * 50 + dk), dk) for dk in dicts]
+    errors = []
+
+    def work(t):
+        try:
+            for rep in range(12):
+                k = (t + rep) % len(datas)
+                if amd.Decompress(streams[k], dict_naive) != datas[k]:
+                    errors.append(("shared", t, rep))
+                s, dk = small[(3 * t + rep) % len(small)]
+                if amd.Decompress(s, dk) != b"abcabcabc" * 50 + dk:
+                    errors.append(("evict", t, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert errors == []

@@ -17,7 +17,13 @@ dist.init_process_group(backend="gloo")
 rank, world, _ = shard.env_rank_world()
 ids = shard.shard_ids(rank, world, 5)
 assert all(shard.owner(b, world) == rank for b in ids)
+strong = shard.batch_shard_ids(rank, world, 7)      # one batch of 7 blobs over the ranks (bench.py's timed leg)
+assert strong == [b for b in shard.shard_ids(rank, world, 7) if b < 7]
+n_all = shard.sum_over_ranks(float(len(strong)))
+assert n_all == 7.0, n_all
+arr = synth.blobs_array(rank, world, 5, 4096)       # the generator bench.py uses: rank, rank + world, ...
 blobs = [synth.blob(b, 4096) for b in ids]
+assert [arr[k].tobytes() for k in range(5)] == blobs
 elapsed = 1.0 + rank          # pretend rank 1 is slower
 t = shard.max_over_ranks(elapsed)
 total = shard.sum_over_ranks(float(sum(map(len, blobs))))
