@@ -134,7 +134,7 @@ struct mi355_lzss_batch {
     uint32_t max_blobs = 0;
     uint64_t cap_elems = 0;  // element capacity of the per-position arrays
     // per-position arrays
-    DevBuf text, sortA, sortB, rkA, rkB, sa_tmp, rlen, sa, isa, lcp, b1, b2, res, adv, kind, exitoff;
+    DevBuf text, sortA, sortB, rkA, rkB, sa_tmp, rlen, sa, isa, lcp, b1, b2, res, adv, kind, exitoff, mpos;
     DevBuf pmin1, pmax1, pmin2, pmax2, samin1, samin2, dlb;  // per 64 entries
     DevBuf cdir;                                        // per 64 ranks and chunk
     DevBuf tbits;                   // per position
@@ -175,7 +175,7 @@ static int batch_reserve(mi355_lzss_batch *b, uint32_t max_blobs, uint64_t elems
         const uint64_t e = elems;
 #define R(buf, bytes_per) if ((rc = b->buf.ensure((size_t)(e * (bytes_per)))) != 0) return rc;
         R(text, 1) R(sortA, 8) R(sortB, 8) R(rlen, 1)  // rkA, rkB, sa_tmp: only with texts for the device-wide suffix sort (upload)
-        R(sa, 4) R(isa, 4) R(lcp, 2) R(res, 4) R(adv, 1) R(kind, 1) R(exitoff, 1) R(tbits, 2)
+        R(sa, 4) R(isa, 4) R(mpos, 4) R(lcp, 2) R(res, 4) R(adv, 1) R(kind, 1) R(exitoff, 1) R(tbits, 2)
 #undef R
         const uint64_t e64 = e / 64 + 1, e256 = e / 256 + 1;
         if ((rc = b->b1.ensure(e64 * 2)) != 0) return rc;
@@ -206,6 +206,7 @@ static SaWork sa_work(mi355_lzss_batch *b) {
     w.rlen = b->rlen.as<uint8_t>();
     w.sa = b->sa.as<int32_t>(); w.isa = b->isa.as<int32_t>();
     w.pairs = b->res.as<uint32_t>();
+    w.mpos = b->mpos.as<uint32_t>();
     w.tmp = b->sa_tmp.as<uint8_t>(); w.tmp_bytes = b->sa_tmp.bytes;
     return w;
 }
@@ -276,7 +277,7 @@ extern "C" void mi355_lzss_batch_destroy(mi355_lzss_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     DevBuf *bufs[] = {&b->text, &b->sortA, &b->sortB, &b->rkA, &b->rkB, &b->sa_tmp, &b->rlen, &b->sa, &b->isa,
-                      &b->lcp, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->dlb, &b->cdir, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
+                      &b->lcp, &b->mpos, &b->b1, &b->b2, &b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->dlb, &b->cdir, &b->res, &b->adv, &b->kind, &b->exitoff, &b->entry, &b->tilebit,
                       &b->tbits, &b->segs, &b->src_off, &b->nbits, &b->out_off, &b->out_len, &b->status, &b->flat, &b->out,
                       &b->d_cin, &b->d_cin_off, &b->d_dout, &b->d_dout_off, &b->d_dlen, &b->d_dstatus};
     for (DevBuf *d : bufs) d->release();
@@ -618,7 +619,11 @@ extern "C" int mi355_lzss_batch_index(mi355_lzss_batch *b, uint32_t blob, int32_
     const Seg &s = b->h_segs[blob];
     size_t N = std::min<size_t>(n_plus_1, (size_t)s.n + 1);
     if (sa) HIP_TRY(hipMemcpy(sa, b->sa.as<int32_t>() + s.off, N * 4, hipMemcpyDeviceToHost));
-    if (isa) HIP_TRY(hipMemcpy(isa, b->isa.as<int32_t>() + s.off, N * 4, hipMemcpyDeviceToHost));
+    if (isa) {  // the suffix sort leaves only the head of the inverse array behind: this view fills the segment's in
+        launch_isa_from_sa(b->segs.as<Seg>() + blob, 1, s.n, b->sa.as<int32_t>(), b->isa.as<int32_t>(), b->stream);
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(hipMemcpy(isa, b->isa.as<int32_t>() + s.off, N * 4, hipMemcpyDeviceToHost));
+    }
     if (lcp) HIP_TRY(hipMemcpy(lcp, b->lcp.as<uint16_t>() + s.off, N * 2, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -640,7 +645,7 @@ extern "C" int mi355_lzss_batch_stage_times(const mi355_lzss_batch *b, const cha
 // holds one copy of the array until the process ends; all calls on a GPU share it, so calls that overlap on one GPU race.
 constexpr uint32_t NOALLOC_MAX_N = MI355_LZSS_NOALLOC_MAX_INPUT;
 constexpr uint64_t NOALLOC_ELEMS = seg_stride(NOALLOC_MAX_N);
-constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)NOALLOC_ELEMS * 40 + (64u << 10);  // ~37 B per position + summaries (checked in noalloc_bind)
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)NOALLOC_ELEMS * 44 + (64u << 10);  // ~41 B per position + summaries (checked in noalloc_bind)
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 // The array's name is a host-side stand-in, not a device address: the address on each device comes from
@@ -678,7 +683,7 @@ static int noalloc_bind(mi355_lzss_ctx *ctx) {
     const uint64_t e = NOALLOC_ELEMS, e64 = e / 64 + 1, e256 = e / 256 + 1;
     const uint64_t nch = (NOALLOC_MAX_N + LZSS_SHORT_WINDOW - 1) / LZSS_SHORT_WINDOW;
     take(b->text, e); take(b->sortA, e * 8); take(b->sortB, e * 8); take(b->rlen, e);
-    take(b->sa, e * 4); take(b->isa, e * 4); take(b->lcp, e * 2); take(b->res, e * 4);
+    take(b->sa, e * 4); take(b->isa, e * 4); take(b->mpos, e * 4); take(b->lcp, e * 2); take(b->res, e * 4);
     take(b->adv, e); take(b->kind, e); take(b->exitoff, e); take(b->tbits, e * 2);
     take(b->b1, e64 * 2); take(b->b2, e64 * 2);
     for (DevBuf *d : {&b->pmin1, &b->pmax1, &b->pmin2, &b->pmax2, &b->samin1, &b->samin2, &b->dlb}) take(*d, e64 * 4);

@@ -8,10 +8,12 @@ namespace lzss {
 struct SaWork {       // batch-wide arrays, indexed [seg.off + k], k in [0, n]
     uint64_t *recA, *recB;               // sort ping-pong (8-byte records, [seg.off + k])
     int32_t *rkA, *rkB;                  // large texts only (sa_large.hip): second suffix buffer, group starts
-    int32_t *sa, *isa;                   // outputs
+    int32_t *sa, *isa;                   // outputs (isa: only the ranks of the first HEAD positions are guaranteed, see launch_isa_from_sa)
     uint8_t *rlen;                       // output: length of the run of equal bytes starting at every position, capped at 255
     uint32_t *pairs;                     // scratch of the main kernel, 4 bytes per suffix ([seg.off + k]; the match results'
                                          // buffer, which nothing uses before the segment is sorted)
+    uint32_t *mpos;                      // scratch of the run-compressed sort (sa_meta_kernel): position word of every item,
+                                         // 4 bytes per suffix ([seg.off + i]); null: every suffix is sorted (sa_build_kernel)
     uint8_t *tmp;                        // scratch of the large-text sort (sa_large.hip), tmp_bytes long; null without large texts
     size_t tmp_bytes;
 };
@@ -21,6 +23,9 @@ constexpr uint32_t SA_BITMAP_MAX_N = 1u << 19;
 // sorted one after the other by launch_sa_large, which synchronises the stream.  Returns 0 or a hipError_t.
 int launch_sa_build(const Seg *d_segs, const Seg *h_segs, uint32_t n_segs, uint32_t max_n, const uint8_t *d_text, const SaWork &wk,
                     hipStream_t stream);
+// isa[sa[k]] = k for whole segments: launch_sa_build leaves only the ranks of the first HEAD positions in SaWork::isa
+// (the run-compressed sort uses the buffer for its items); the index views of the C ABI call this
+void launch_isa_from_sa(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const int32_t *d_sa, int32_t *d_isa, hipStream_t stream);
 // sa_large.hip: one text of more than SA_BITMAP_MAX_N suffixes on the whole device (rocPRIM radix sort per doubling round)
 size_t sa_large_temp_bytes(uint32_t N);
 int launch_sa_large(const Seg &sg, const uint8_t *d_text, const SaWork &wk, hipStream_t stream);

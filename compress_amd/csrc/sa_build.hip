@@ -143,6 +143,10 @@ constexpr int SA_ISA_CH = 13;
 #endif
 constexpr uint32_t SA_LATE_DIV = SA_LATE_DIVISOR;  // rounds with at most N / this active suffixes skip the sweep
 constexpr int SA_RUN_CAP = 254;  // runs of equal symbols are told apart by length up to here
+// run-compressed sort (sa_meta_kernel): item i of a text starts at byte mpos[i] & MP_POS_MASK; bits 20-27 hold that
+// byte, bit 28 says that the item is one byte of a run with at least SA_RUN_CAP bytes to go ("deep")
+constexpr uint32_t MP_POS_MASK = (1u << 20) - 1u;
+constexpr int MP_BYTE_SHIFT = 20, MP_DEEP_SHIFT = 28;
 
 // Length of the run of equal bytes that starts at position e of the text (1 at and past its end), exact up to 257:
 // the lanes of a wave hold 64 consecutive positions and read the run off five ballots of "byte == next byte".
@@ -206,6 +210,7 @@ struct SaLds {
     int32_t *tpos;     // [NB] scratch: digit counts of a late round's second keys (low digit)
     int32_t *hl, *hh;  // [NB] digit counts of the next round's keys (low / high digit)
     int32_t *hy;       // [NB] digit counts of a late round's second keys (high digit; the low digit's sit in tpos)
+    int32_t *hsec;     // [NB] sa_meta_kernel: entries per section of the expansion (items by their byte + 1)
     int32_t *wtot;     // [16] tile entries per wave of bin threads
     uint16_t *whist;   // [SAM_WAVES / 2][NB][2] entries of the current tile per bin and wave (zero between tiles): waves
                        // 2k and 2k + 1 share a 32-bit word, a row holds the NB bins, so a wave's lanes with different
@@ -220,7 +225,8 @@ struct SaLds {
         hl = tpos + NB;
         hh = hl + NB;
         hy = hh + NB;
-        wtot = hy + NB;
+        hsec = hy + NB;
+        wtot = hsec + NB;
         whist = (uint16_t *)(wtot + 16);
         woff = whist + SAM_WAVES * NB;
         mtab = (uint64_t *)(woff + SAM_WAVES * NB);
@@ -228,17 +234,18 @@ struct SaLds {
     static __device__ inline int cell(int d, int w) { return ((((w >> 1) * NB) + d) << 1) | (w & 1); }
     // words: bitmap words (even)
     static size_t bytes(uint32_t words) {
-        return (size_t)words * 4 + ((size_t)NB * 6 + 16) * 4 + (size_t)SAM_WAVES * NB * 4 +
+        return (size_t)words * 4 + ((size_t)NB * 7 + 16) * 4 + (size_t)SAM_WAVES * NB * 4 +
                (SA_MTAB ? (size_t)SAM_WAVES * mtab_entries() * 8 : 0);
     }
 };
 
-struct SaCarry {
+struct alignas(16) SaCarry {   // (its size sets the offset of the dynamic LDS behind it, whose peer table holds 64-bit words)
     int32_t a[2][SAM_WAVES];
     int32_t b[2][SAM_WAVES];
     int32_t wcount[SAM_WAVES];
     int32_t fin_cnt[8];   // small groups listed for sa_finish, by size (2 .. 8 at [0 .. 6]); [7]: suffixes it has finished
     int32_t bin_cur[64];  // initial regroup: (position, rank) pairs written so far per chunk of 2^SA_ISA_CH positions
+    int32_t next_sec;     // sa_meta_kernel: next section of the expansion a wave may take
 };
 
 // lanes of the wave (among `valid`) holding the same digit as this lane.  The most frequent digits are found
@@ -791,7 +798,11 @@ __device__ inline int finish_group(const uint8_t *T, uint32_t n, const uint32_t 
 // suffixes finished.  d0: symbols the members of a group are known to share.
 template <int DB>
 __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint32_t *fin_list, uint32_t fin_N, int32_t *sa,
-                                     int32_t *rk, const uint8_t *T, uint32_t n, int d0, int tid, uint32_t *pairs = nullptr) {
+                                     int32_t *rk, const uint8_t *T, uint32_t n, int d0, int tid, uint32_t *pairs = nullptr,
+                                     const uint32_t *mpos = nullptr) {
+    // mpos: the suffixes are those of the run-compressed text (sa_meta_kernel): members are item indices, item i starts at
+    // byte mpos[i] & MP_POS_MASK, d0 counts items; equal items cover equal byte counts, so the bytes the members share are
+    // those of the first member's d0 items, and the byte compare decides the items' order
     // pairs: after the initial regroup (binned rank store) - the ranks of ALL listed members go to the chunk streams
     constexpr int NB = 1 << DB;
     if (SA_FIN_G < 2) return 0;
@@ -806,12 +817,23 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
             for (int j = 0; j < z; ++j) p[j] = (uint32_t)sa[slot0 + j] & 0x7FFFFFFFu;
             int place[SA_FIN_G];
 #if SA_FIN_SHARED
+            uint32_t pb_[SA_FIN_G];   // byte positions of the members
+            int d0b = d0;             // bytes the members share
+            if (mpos) {
+#pragma unroll
+                for (int j = 0; j < z; ++j) pb_[j] = mpos[p[j]] & MP_POS_MASK;
+                d0b = (int)((mpos[p[0] + (uint32_t)d0] & MP_POS_MASK) - pb_[0]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < z; ++j) pb_[j] = p[j];
+            }
+            const uint32_t *pb = pb_;
             int ok = 0;
-            if (z == 2) ok = finish_group<2>(T, n, p, d0, SA_FIN_SPAN, place);
-            else if (z == 3) ok = finish_group<3>(T, n, p, d0, SA_FIN_SPAN, place);
-            else if (z == 4) ok = finish_group<(SA_FIN_G >= 4 ? 4 : 2)>(T, n, p, d0, SA_FIN_SPAN, place);
-            else if (z == 5) ok = finish_group<(SA_FIN_G >= 5 ? 5 : 2)>(T, n, p, d0, SA_FIN_SPAN, place);
-            else if (z == 6) ok = finish_group<(SA_FIN_G >= 6 ? 6 : 2)>(T, n, p, d0, SA_FIN_SPAN, place);
+            if (z == 2) ok = finish_group<2>(T, n, pb, d0b, SA_FIN_SPAN, place);
+            else if (z == 3) ok = finish_group<3>(T, n, pb, d0b, SA_FIN_SPAN, place);
+            else if (z == 4) ok = finish_group<(SA_FIN_G >= 4 ? 4 : 2)>(T, n, pb, d0b, SA_FIN_SPAN, place);
+            else if (z == 5) ok = finish_group<(SA_FIN_G >= 5 ? 5 : 2)>(T, n, pb, d0b, SA_FIN_SPAN, place);
+            else if (z == 6) ok = finish_group<(SA_FIN_G >= 6 ? 6 : 2)>(T, n, pb, d0b, SA_FIN_SPAN, place);
 #ifdef SA_PROFILE_ROUNDS
             if (ok != 1) atomicAdd(&cy.fin_cnt[ok == 2 ? 6 : 5], z);
 #endif
@@ -870,169 +892,14 @@ __device__ inline uint32_t sa_finish(const SaLds<DB> &L, SaCarry &cy, const uint
     return done;
 }
 
+// ---- initial order: SaInit<DB>::DIGITS LSD passes over the NN records (36- or 45-bit key << SHIFT | index) in recB, least
+//      significant digit first, ping-pong with recA; the digit counts come from the sweep that built the records
 template <int DB>
-__global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM_WAVES * SA_WGS_PER_CU / 4, SAM_WAVES * SA_WGS_PER_CU / 4))) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
+__device__ inline void sa_initial_sort(const SaLds<DB> &L, uint64_t *recB, uint64_t *recA, uint32_t N, const int32_t *hZ,
+                                       const int32_t *hY, const int32_t *hX, const int32_t *hC, const int32_t *hS, int tid) {
     constexpr int NB = 1 << DB;
-    constexpr int MASK = NB - 1;
-    __shared__ SaCarry cy;
-    extern __shared__ uint32_t dyn_lds[];
-    const Seg sg = segs[blockIdx.x];
-    const uint8_t *T = text + sg.off;
-    const uint32_t n = sg.n;
-    const uint32_t N = n + 1;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    int32_t *sa = wk.sa + sg.off, *rk = wk.isa + sg.off;
-
-    if (N == 1) {
-        if (tid == 0) {
-            sa[0] = 0;
-            rk[0] = 0;
-        }
-        return;
-    }
-    const uint32_t words = sa_bitmap_words<DB>(N);
-    const SaLds<DB> L(dyn_lds, words);
-    uint64_t *recA = wk.recA + sg.off, *recB = wk.recB + sg.off;
-
+    const int lane = tid & 63, w = tid >> 6;
     SA_PROF_DECL
-    if (tid < 8) cy.fin_cnt[tid] = 0;
-    if (tid < 64) cy.bin_cur[tid] = 0;
-    for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;
-    for (int x = tid; x < 6 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh, hy
-    for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
-    if (SA_MTAB)
-        for (int x = tid; x < SAM_WAVES * SaLds<DB>::mtab_entries(); x += SAM_THREADS) L.mtab[x] = 0;
-    __syncthreads();
-    SA_PROF(20)
-
-    // ---- initial keys.  36 bits per suffix, 4 digits of 9: (first symbol c, run code, x, y) where the run code
-    //      encodes the length rl of the run of c the suffix starts with and x, y are the two symbols after the
-    //      run (0 = sentinel, byte + 1 otherwise).  Among suffixes starting with c, those whose run ends in a
-    //      smaller symbol come first, shorter runs first (codes 1..253), then runs of >= SA_RUN_CAP (code 255, x
-    //      and y left out), then those whose run ends in a larger symbol, longer runs first (codes 511 - rl).  The
-    //      key order is the suffix order, every key group shares at least 3 symbols, and suffixes inside long
-    //      runs - most of the deep groups of zero-heavy inputs - start out almost sorted (measured on the bench
-    //      blobs: the doubling rounds move 0.98 N suffixes in total instead of 2.44 N after a plain 4-symbol key).
-    //      One sweep builds the records (key << 20 | suffix) in text order and counts the four digits.
-    int32_t *hY = (int32_t *)L.act, *hX = hY + NB, *hC = L.hl, *hS = L.hh;  // act is free until the first regroup
-    int32_t *hZ = L.hy;                                                       // (a late round's array)
-    {
-        // Every wave sweeps a contiguous range of 64-position blocks, so the "byte == next byte" ballots that give the
-        // run lengths slide: a block's run lengths read the flags of itself and the next four blocks (exact up to 257),
-        // and only the fifth is new in each step - one two-byte load per lane and step instead of ten byte loads.
-        const uint32_t nblk = (N + 63) / 64, per = (nblk + SAM_WAVES - 1) / SAM_WAVES;
-        // (the wave's index as an SGPR: with bounds the compiler takes for divergent, this loop was compiled with exec
-        // masking, its ballots in VGPRs and its loads waited for where they are issued)
-        const uint32_t wu = (uint32_t)wave_index(tid);
-        const uint32_t bb = wu * per, be = bb + per < nblk ? bb + per : nblk;
-        // The loads of a step are issued ahead of their use (4 waves per SIMD hide little latency by themselves, and a
-        // step that waited for its flag load and then for the load behind its run took 2.6 us): the flag bytes of a
-        // block arrive two steps before their ballot, and the symbols behind the runs of a block are requested
-        // SA_SWEEP_AHEAD steps before the block's records are built.
-        constexpr int PD = SA_SWEEP_AHEAD;
-        auto raw_load = [&](uint32_t blk) -> uint32_t {
-            const uint32_t q = blk * 64 + (uint32_t)lane;
-            uint16_t v = 0;
-            if (q < N) __builtin_memcpy(&v, T + q, 2);  // (zero padding follows the text)
-            return v;
-        };
-        auto flags_of = [&](uint32_t blk, uint32_t v) -> uint64_t {
-            const uint32_t q = blk * 64 + (uint32_t)lane;
-            return __ballot(q + 1 < n && (v & 0xFFu) == (v >> 8));
-        };
-        uint64_t E1 = 0, E2 = 0, E3 = 0, E4 = 0;
-        uint32_t rawA = 0, rawB = 0;
-        if (bb < be) {
-            const uint32_t r0 = raw_load(bb), r1 = raw_load(bb + 1), r2 = raw_load(bb + 2), r3 = raw_load(bb + 3);
-            rawA = raw_load(bb + 4);
-            rawB = raw_load(bb + 5);
-            E1 = flags_of(bb, r0);
-            E2 = flags_of(bb + 1, r1);
-            E3 = flags_of(bb + 2, r2);
-            E4 = flags_of(bb + 3, r3);
-        }
-        int p_rl[PD];
-        uint32_t p_v[PD], p_s[PD];
-#pragma unroll
-        for (int t = 0; t < PD; ++t) {
-            p_rl[t] = 1;
-            p_v[t] = p_s[t] = 0;
-        }
-        for (uint32_t c = bb; c < be + PD && bb < be; ++c) {
-            // ---- block c: run lengths from the sliding flags, loads of the symbols behind the runs
-            int n_rl = 1;
-            uint32_t n_v = 0, n_s = 0;
-            if (c < be) {
-                const uint64_t E0 = E1;
-                E1 = E2; E2 = E3; E3 = E4;
-                E4 = flags_of(c + 4, rawA);
-                rawA = rawB;
-                rawB = raw_load(c + 6);
-                const uint32_t e = c * 64 + (uint32_t)lane;
-                // ones from this lane's flag on (run_length_64 on the sliding flags)
-                const uint64_t x0 = E0 >> lane;
-                int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);
-                if (rl == 64 - lane) {
-                    const uint64_t Et[4] = {E1, E2, E3, E4};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int rt = Et[t] == ~0ull ? 64 : (int)__builtin_ctzll(~Et[t]);
-                        rl += rt;
-                        if (rt < 64) break;
-                    }
-                }
-                n_rl = rl + 1;
-                if (e < N) {
-                    n_s = T[e];
-                    if (n_rl < SA_RUN_CAP) __builtin_memcpy(&n_v, T + e + (uint32_t)n_rl, 4);  // (the text is zero padded)
-                }
-            }
-            // ---- block c - PD: records and digit counts
-            if (c >= bb + PD) {
-                const uint32_t e = (c - PD) * 64 + (uint32_t)lane;
-                const int rl = p_rl[0];
-                const uint32_t v = p_v[0];
-                const bool valid = e < N;
-                if (valid) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
-                int dZ = 0, dY = 0, dX = 0, dC = 0, dS = 0;
-                if (valid) {
-                    dS = e < n ? (int)p_s[0] + 1 : 0;
-                    if (rl >= SA_RUN_CAP) {
-                        dC = 255;
-                    } else {
-                        const uint32_t q = e + (uint32_t)rl;
-                        dX = q < n ? (int)(v & 0xFFu) + 1 : 0;
-                        dY = q + 1 < n ? (int)((v >> 8) & 0xFFu) + 1 : 0;
-                        dZ = q + 2 < n ? (int)((v >> 16) & 0xFFu) + 1 : 0;
-                        dC = dX < dS ? rl : 511 - rl;
-                    }
-                    uint64_t rec = ((((uint64_t)dS << 9) | (uint64_t)dC) << 9) | (uint64_t)dX;
-                    if (SaInit<DB>::DIGITS >= 4) rec = (rec << 9) | (uint64_t)dY;
-                    if (SaInit<DB>::Z) rec = (rec << 9) | (uint64_t)dZ;
-                    rec = (rec << SaInit<DB>::SHIFT) | (uint64_t)e;
-                    recB[e] = rec;
-                }
-                if (SaInit<DB>::Z) digit_count(hZ, dZ, valid, lane);
-                if (SaInit<DB>::DIGITS >= 4) digit_count(hY, dY, valid, lane);
-                digit_count(hX, dX, valid, lane);
-                digit_count(hC, dC, valid, lane);
-                digit_count(hS, dS, valid, lane);
-            }
-#pragma unroll
-            for (int t = 0; t + 1 < PD; ++t) {
-                p_rl[t] = p_rl[t + 1];
-                p_v[t] = p_v[t + 1];
-                p_s[t] = p_s[t + 1];
-            }
-            p_rl[PD - 1] = n_rl;
-            p_v[PD - 1] = n_v;
-            p_s[PD - 1] = n_s;
-        }
-    }
-    __syncthreads();
-    SA_PROF(21)
-
-    // ---- initial order: 4 LSD passes over the records, least significant digit (y) first
     {
         const uint64_t *rin = recB;
         uint64_t *rout = recA;
@@ -1080,22 +947,18 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             rout = (rout == recA) ? recB : recA;
         }
     }
-    const uint64_t *rcur = (SaInit<DB>::DIGITS & 1) ? recA : recB;
-    for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh
-    for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;  // held two digit histograms so far
-    __syncthreads();
+}
 
-    SA_PROF(15)
-    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid, (uint32_t *)(rcur == recA ? recB : recA), N, wk.pairs + sg.off);
-    SA_PROF(4)
-    m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), N, sa, rk, T, n, (int)SaInit<DB>::H0, tid,
-                       isa_binned<DB>() ? wk.pairs + sg.off : nullptr);
-    if (isa_binned<DB>()) isa_flush<DB>(L, wk.pairs + sg.off, N, rk, tid);
-    SA_PROF(19)
-    uint32_t h = SaInit<DB>::H0;  // every group of the initial keys shares at least that many symbols
-#ifdef SA_PROFILE_ROUNDS  // (a device printf costs far more than a round: not in the clocked build)
-    if (blockIdx.x == 0 && tid == 0) printf("after init: N=%u m=%u\n", N, m);
-#endif
+// ---- the doubling rounds: NN suffixes (of the text itself, or - mpos != nullptr - of the run-compressed text whose
+//      item i starts at byte mpos[i] & MP_POS_MASK of T), m of them still sharing their group, which share h symbols
+template <int DB>
+__device__ inline void sa_rounds(const SaLds<DB> &L, SaCarry &cy, uint64_t *recA, uint64_t *recB, int32_t *sa, int32_t *rk,
+                                 uint32_t N, uint32_t words, uint32_t m, uint32_t h, const uint8_t *T, uint32_t n,
+                                 const uint32_t *mpos, int tid, int max_rounds) {
+    constexpr int NB = 1 << DB;
+    constexpr int MASK = NB - 1;
+    const int lane = tid & 63, w = tid >> 6;
+    SA_PROF_DECL
     while (m != 0 && h < N && --max_rounds >= 0) {
 #ifdef SA_PROFILE_ROUNDS
         if (blockIdx.x == 0 && tid == 0) printf("round h=%u m=%u late=%d\n", h, m, (int)((uint64_t)m * SA_LATE_DIV <= N));
@@ -1241,7 +1104,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         // ---- D: new groups
         m = sa_regroup<false, DB>(L, cy, recB, m, sa, rk, tid, (uint32_t *)recA, N);
         SA_PROF(14)
-        m -= sa_finish<DB>(L, cy, (const uint32_t *)recA, N, sa, rk, T, n, (int)(2 * h < (1u << 20) ? 2 * h : (1u << 20)), tid);
+        m -= sa_finish<DB>(L, cy, (const uint32_t *)recA, N, sa, rk, T, n, (int)(2 * h < (1u << 20) ? 2 * h : (1u << 20)), tid, nullptr, mpos);
         SA_PROF(18)
         h *= 2;
     }
@@ -1249,8 +1112,788 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         __syncthreads();
         for (uint32_t j = tid; j < N; j += SAM_THREADS) sa[j] &= 0x7FFFFFFF;
     }
+}
+
+template <int DB>
+__global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM_WAVES * SA_WGS_PER_CU / 4, SAM_WAVES * SA_WGS_PER_CU / 4))) void sa_build_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
+    constexpr int NB = 1 << DB;
+    constexpr int MASK = NB - 1;
+    __shared__ SaCarry cy;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+    const Seg sg = segs[blockIdx.x];
+    const uint8_t *T = text + sg.off;
+    const uint32_t n = sg.n;
+    const uint32_t N = n + 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int32_t *sa = wk.sa + sg.off, *rk = wk.isa + sg.off;
+
+    if (N == 1) {
+        if (tid == 0) {
+            sa[0] = 0;
+            rk[0] = 0;
+        }
+        return;
+    }
+    const uint32_t words = sa_bitmap_words<DB>(N);
+    const SaLds<DB> L(dyn_lds, words);
+    uint64_t *recA = wk.recA + sg.off, *recB = wk.recB + sg.off;
+
+    SA_PROF_DECL
+    if (tid < 8) cy.fin_cnt[tid] = 0;
+    if (tid < 64) cy.bin_cur[tid] = 0;
+    for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;
+    for (int x = tid; x < 7 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh, hy, hsec
+    for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
+    if (SA_MTAB)
+        for (int x = tid; x < SAM_WAVES * SaLds<DB>::mtab_entries(); x += SAM_THREADS) L.mtab[x] = 0;
+    __syncthreads();
+    SA_PROF(20)
+
+    // ---- initial keys.  36 bits per suffix, 4 digits of 9: (first symbol c, run code, x, y) where the run code
+    //      encodes the length rl of the run of c the suffix starts with and x, y are the two symbols after the
+    //      run (0 = sentinel, byte + 1 otherwise).  Among suffixes starting with c, those whose run ends in a
+    //      smaller symbol come first, shorter runs first (codes 1..253), then runs of >= SA_RUN_CAP (code 255, x
+    //      and y left out), then those whose run ends in a larger symbol, longer runs first (codes 511 - rl).  The
+    //      key order is the suffix order, every key group shares at least 3 symbols, and suffixes inside long
+    //      runs - most of the deep groups of zero-heavy inputs - start out almost sorted (measured on the bench
+    //      blobs: the doubling rounds move 0.98 N suffixes in total instead of 2.44 N after a plain 4-symbol key).
+    //      One sweep builds the records (key << 20 | suffix) in text order and counts the four digits.
+    int32_t *hY = (int32_t *)L.act, *hX = hY + NB, *hC = L.hl, *hS = L.hh;  // act is free until the first regroup
+    int32_t *hZ = L.hy;                                                       // (a late round's array)
+    {
+        // Every wave sweeps a contiguous range of 64-position blocks, so the "byte == next byte" ballots that give the
+        // run lengths slide: a block's run lengths read the flags of itself and the next four blocks (exact up to 257),
+        // and only the fifth is new in each step - one two-byte load per lane and step instead of ten byte loads.
+        const uint32_t nblk = (N + 63) / 64, per = (nblk + SAM_WAVES - 1) / SAM_WAVES;
+        // (the wave's index as an SGPR: with bounds the compiler takes for divergent, this loop was compiled with exec
+        // masking, its ballots in VGPRs and its loads waited for where they are issued)
+        const uint32_t wu = (uint32_t)wave_index(tid);
+        const uint32_t bb = wu * per, be = bb + per < nblk ? bb + per : nblk;
+        // The loads of a step are issued ahead of their use (4 waves per SIMD hide little latency by themselves, and a
+        // step that waited for its flag load and then for the load behind its run took 2.6 us): the flag bytes of a
+        // block arrive two steps before their ballot, and the symbols behind the runs of a block are requested
+        // SA_SWEEP_AHEAD steps before the block's records are built.
+        constexpr int PD = SA_SWEEP_AHEAD;
+        auto raw_load = [&](uint32_t blk) -> uint32_t {
+            const uint32_t q = blk * 64 + (uint32_t)lane;
+            uint16_t v = 0;
+            if (q < N) __builtin_memcpy(&v, T + q, 2);  // (zero padding follows the text)
+            return v;
+        };
+        auto flags_of = [&](uint32_t blk, uint32_t v) -> uint64_t {
+            const uint32_t q = blk * 64 + (uint32_t)lane;
+            return __ballot(q + 1 < n && (v & 0xFFu) == (v >> 8));
+        };
+        uint64_t E1 = 0, E2 = 0, E3 = 0, E4 = 0;
+        uint32_t rawA = 0, rawB = 0;
+        if (bb < be) {
+            const uint32_t r0 = raw_load(bb), r1 = raw_load(bb + 1), r2 = raw_load(bb + 2), r3 = raw_load(bb + 3);
+            rawA = raw_load(bb + 4);
+            rawB = raw_load(bb + 5);
+            E1 = flags_of(bb, r0);
+            E2 = flags_of(bb + 1, r1);
+            E3 = flags_of(bb + 2, r2);
+            E4 = flags_of(bb + 3, r3);
+        }
+        int p_rl[PD];
+        uint32_t p_v[PD], p_s[PD];
+#pragma unroll
+        for (int t = 0; t < PD; ++t) {
+            p_rl[t] = 1;
+            p_v[t] = p_s[t] = 0;
+        }
+        for (uint32_t c = bb; c < be + PD && bb < be; ++c) {
+            // ---- block c: run lengths from the sliding flags, loads of the symbols behind the runs
+            int n_rl = 1;
+            uint32_t n_v = 0, n_s = 0;
+            if (c < be) {
+                const uint64_t E0 = E1;
+                E1 = E2; E2 = E3; E3 = E4;
+                E4 = flags_of(c + 4, rawA);
+                rawA = rawB;
+                rawB = raw_load(c + 6);
+                const uint32_t e = c * 64 + (uint32_t)lane;
+                // ones from this lane's flag on (run_length_64 on the sliding flags)
+                const uint64_t x0 = E0 >> lane;
+                int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);
+                if (rl == 64 - lane) {
+                    const uint64_t Et[4] = {E1, E2, E3, E4};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int rt = Et[t] == ~0ull ? 64 : (int)__builtin_ctzll(~Et[t]);
+                        rl += rt;
+                        if (rt < 64) break;
+                    }
+                }
+                n_rl = rl + 1;
+                if (e < N) {
+                    n_s = T[e];
+                    if (n_rl < SA_RUN_CAP) __builtin_memcpy(&n_v, T + e + (uint32_t)n_rl, 4);  // (the text is zero padded)
+                }
+            }
+            // ---- block c - PD: records and digit counts
+            if (c >= bb + PD) {
+                const uint32_t e = (c - PD) * 64 + (uint32_t)lane;
+                const int rl = p_rl[0];
+                const uint32_t v = p_v[0];
+                const bool valid = e < N;
+                if (valid) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
+                int dZ = 0, dY = 0, dX = 0, dC = 0, dS = 0;
+                if (valid) {
+                    dS = e < n ? (int)p_s[0] + 1 : 0;
+                    if (rl >= SA_RUN_CAP) {
+                        dC = 255;
+                    } else {
+                        const uint32_t q = e + (uint32_t)rl;
+                        dX = q < n ? (int)(v & 0xFFu) + 1 : 0;
+                        dY = q + 1 < n ? (int)((v >> 8) & 0xFFu) + 1 : 0;
+                        dZ = q + 2 < n ? (int)((v >> 16) & 0xFFu) + 1 : 0;
+                        dC = dX < dS ? rl : 511 - rl;
+                    }
+                    uint64_t rec = ((((uint64_t)dS << 9) | (uint64_t)dC) << 9) | (uint64_t)dX;
+                    if (SaInit<DB>::DIGITS >= 4) rec = (rec << 9) | (uint64_t)dY;
+                    if (SaInit<DB>::Z) rec = (rec << 9) | (uint64_t)dZ;
+                    rec = (rec << SaInit<DB>::SHIFT) | (uint64_t)e;
+                    recB[e] = rec;
+                }
+                if (SaInit<DB>::Z) digit_count(hZ, dZ, valid, lane);
+                if (SaInit<DB>::DIGITS >= 4) digit_count(hY, dY, valid, lane);
+                digit_count(hX, dX, valid, lane);
+                digit_count(hC, dC, valid, lane);
+                digit_count(hS, dS, valid, lane);
+            }
+#pragma unroll
+            for (int t = 0; t + 1 < PD; ++t) {
+                p_rl[t] = p_rl[t + 1];
+                p_v[t] = p_v[t + 1];
+                p_s[t] = p_s[t + 1];
+            }
+            p_rl[PD - 1] = n_rl;
+            p_v[PD - 1] = n_v;
+            p_s[PD - 1] = n_s;
+        }
+    }
+    __syncthreads();
+    SA_PROF(21)
+
+    sa_initial_sort<DB>(L, recB, recA, N, hZ, hY, hX, hC, hS, tid);
+    const uint64_t *rcur = (SaInit<DB>::DIGITS & 1) ? recA : recB;
+    for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh
+    for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;  // held two digit histograms so far
+    __syncthreads();
+
+    SA_PROF(15)
+    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, N, sa, rk, tid, (uint32_t *)(rcur == recA ? recB : recA), N, wk.pairs + sg.off);
+    SA_PROF(4)
+    m -= sa_finish<DB>(L, cy, (const uint32_t *)(rcur == recA ? recB : recA), N, sa, rk, T, n, (int)SaInit<DB>::H0, tid,
+                       isa_binned<DB>() ? wk.pairs + sg.off : nullptr);
+    if (isa_binned<DB>()) isa_flush<DB>(L, wk.pairs + sg.off, N, rk, tid);
+    SA_PROF(19)
+    uint32_t h = SaInit<DB>::H0;  // every group of the initial keys shares at least that many symbols
+#ifdef SA_PROFILE_ROUNDS  // (a device printf costs far more than a round: not in the clocked build)
+    if (blockIdx.x == 0 && tid == 0) printf("after init: N=%u m=%u\n", N, m);
+#endif
+    sa_rounds<DB>(L, cy, recA, recB, sa, rk, N, words, m, h, T, n, nullptr, tid, max_rounds);
     SA_PROF(15)
     SA_PROF_PRINT
+}
+
+// ---- run-compressed suffix sort ------------------------------------------------------------------------------------
+// 60 % of the positions of calldata-like texts lie inside a run of equal bytes behind its first byte.  Their suffixes
+// need no sorting of their own: the suffix at q inside a run of c that ends at e is c^(e - q) followed by the suffix at e,
+// so among the suffixes that start with the same number of c's (and end their run the same way) it sorts by the rank of
+// the suffix at e.  sa_meta_kernel therefore sorts ITEMS only: the first position of every run, and - runs of more than
+// 253 bytes - every position with at least 253 bytes of the run to go (a run is cut into single "deep" bytes and a final
+// chunk of 253).  An item's symbol is (byte + 1, run code of its chunk: length l if the chunk is followed by a smaller
+// byte or the end, 255 for a deep byte, 511 - l if followed by a larger byte); equal symbols cover equal byte counts and
+// the lexicographic order of the symbol sequences is the order of the suffixes (the run code orders a shorter run
+// before or behind a longer one exactly as the byte behind it does), so the items are sorted by the machinery above -
+// prefix doubling in ITEM space: keys of two symbols, h counted in items, texts of ~0.4 N symbols without any runs -
+// with the finisher comparing bytes at the items' positions.  The EXPANSION then writes the whole suffix array in one
+// sweep over the sorted items: in rank order, item u is the tail of the chunk before it (entry: tail position, chunk
+// length l, type), entries are scattered by the chunk's byte (sections), and inside a section the records
+// (tail - k, k = 1 .. l) of run code k are the entries with l >= k in rank order - level k is the previous level
+// filtered, dense in every lane, and lands in the suffix array as one contiguous run.
+#ifndef SA_META
+#define SA_META 1
+#endif
+#ifdef SA_META_CHECK  // debug builds: every index of the expansion is checked, a violation is reported and skipped
+__device__ int g_meta_bad = 0;
+#define MCHK(cond, site, a_, b_) ((cond) ? true : (atomicAdd(&g_meta_bad, 1) < 40 ? (printf("META CHECK site %d blk %d tid %d: %lld %lld\n", site, (int)blockIdx.x, (int)threadIdx.x, (long long)(a_), (long long)(b_)), false) : false))
+#else
+#define MCHK(cond, site, a_, b_) true
+#endif
+#ifdef SA_META_PROFILE  // per-phase clocks of a few workgroups (debug builds only)
+#define MPH(i) { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); const long long t_ = clock64(); mph[i] = t_ - mph_last; mph_last = t_; }
+#define MPH_DECL long long mph[16] = {}; long long mph_last = clock64();
+#define MPH_PRINT if (tid == 0 && (blockIdx.x % 997) == 0) printf("blk %d N %u items %u | init %lld sweep %lld passB %lld sort %lld regroup %lld finish %lld flush %lld rounds %lld P %lld scan %lld Xbig %lld Xsmall %lld flush2 %lld\n", (int)blockIdx.x, N, NM, mph[0], mph[1], mph[2], mph[3], mph[4], mph[5], mph[6], mph[7], mph[8], mph[9], mph[10], mph[11], mph[12]);
+#else
+#define MPH(i)
+#define MPH_DECL
+#define MPH_PRINT
+#endif
+constexpr int XP_W = 512;            // entries a wave expands at a time (its private list in LDS)
+constexpr uint32_t XP_BIG = 4096;    // sections of at least this many entries are expanded by all waves together
+constexpr int XP_TAB = 512;          // level table: [k] chunks followed by a smaller byte, [255] deep bytes, [256 + k] by a larger one
+
+// histogram of (type, chunk length) of entries [a, b) into tab (zeroed); one wave.  Returns the largest chunk length.
+__device__ inline int xp_count(const uint32_t *ent, uint32_t a, uint32_t b, int32_t *tab, int lane) {
+    int mx = 1;
+    for (uint32_t x = a + (uint32_t)lane; x < b; x += 64) {
+        const uint32_t e = ent[x];
+        const uint32_t ty = e >> 28, ell = (e >> 20) & 0xFFu;
+        atomicAdd(&tab[ty == 2u ? 255u : (ty == 1u ? 256u + ell : ell)], 1);
+        mx = (int)ell > mx ? (int)ell : mx;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return wave_max(mx);
+}
+// tab[k] = number of entries of that type with chunk length >= k (in place, k = 1 .. 253 of both types); one wave.
+// qmax: no chunk is longer than 64 qmax + 63 (the 64-entry stretches of the tables above that are zero and stay so)
+__device__ inline void xp_levels(int32_t *tab, int lane, int qmax) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int carry = 0;
+        for (int q = qmax; q >= 0; --q) {
+            const int idx = q * 64 + lane;
+            const bool in = idx >= 1 && idx <= 253;
+            const int v = in ? tab[half * 256 + idx] : 0;
+            const int pre = wave_incl_add(v, lane);
+            const int tot = lane_value(pre, 63);
+            if (in) tab[half * 256 + idx] = carry + tot - pre + v;
+            carry += tot;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// out[.] = first slot of every level's records in the section that starts at slot s0, from the section's level counts
+// cnt: run codes ascending - levels 1 .. 253 of the chunks followed by a smaller byte, the deep bytes, levels 253 .. 1 of
+// the chunks followed by a larger byte.  One wave; out may be cnt.
+__device__ inline void xp_offsets(const int32_t *cnt, int32_t *out, int s0, int lane, int qmax) {
+    int c0[4], c1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = q * 64 + lane;
+        const bool in = q <= qmax && idx >= 1 && idx <= 253;
+        c0[q] = in ? cnt[idx] : 0;
+        c1[q] = in ? cnt[256 + idx] : 0;
+    }
+    const int deep = cnt[255];
+    __builtin_amdgcn_wave_barrier();
+    int carry = s0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // smaller type: ascending k
+        if (q > qmax) continue;
+        const int idx = q * 64 + lane;
+        const int pre = wave_incl_add(c0[q], lane);
+        if (idx >= 1 && idx <= 253) out[idx] = carry + pre - c0[q];
+        carry += lane_value(pre, 63);
+    }
+    if (lane == 0) out[255] = carry;
+    carry += deep;
+#pragma unroll
+    for (int q = 3; q >= 0; --q) {  // larger type: descending k
+        if (q > qmax) continue;
+        const int idx = q * 64 + lane;
+        const int pre = wave_incl_add(c1[q], lane);
+        const int tot = lane_value(pre, 63);
+        if (idx >= 1 && idx <= 253) out[256 + idx] = carry + tot - pre;   // the levels above k come first
+        carry += tot;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// Entries [a, b) of one section, level by level: level k writes the records of the entries with l >= k (run[] holds the
+// next free slot of every level and moves on), then drops the entries with l == k from the wave's list.  One wave.
+__device__ inline void xp_expand(const uint32_t *ent, uint32_t a, uint32_t b, int32_t *run, uint32_t *buf, int32_t *sa,
+                                 int32_t *rk, int lane, uint32_t N) {
+    (void)N;
+    const uint64_t lt = lanemask_lt(lane);
+    for (uint32_t a0 = a; a0 < b; a0 += XP_W) {
+        uint32_t cur = b - a0 < (uint32_t)XP_W ? b - a0 : (uint32_t)XP_W;
+        for (uint32_t x = lane; x < cur; x += 64) buf[x] = ent[a0 + x];
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = 1; cur > 0; ++k) {
+            int r0 = run[k], r1 = run[256 + k], r2 = run[255];
+            uint32_t keep = 0;
+            for (uint32_t c0 = 0; c0 < cur; c0 += 64) {
+                const uint32_t x = c0 + (uint32_t)lane;
+                const bool valid = x < cur;
+                const uint32_t e = valid ? buf[x] : 0u;
+                const uint32_t ty = e >> 28, ell = (e >> 20) & 0xFFu;
+                const uint64_t b0 = __ballot(valid && ty == 0u), b1 = __ballot(valid && ty == 1u), b2 = __ballot(valid && ty == 2u);
+                if (valid && MCHK((e & MP_POS_MASK) >= k && (e & MP_POS_MASK) - k < N && ty <= 2u && k <= 253u, 10, e, k)) {
+                    const int slot = ty == 0u ? r0 + __popcll(b0 & lt) : (ty == 1u ? r1 + __popcll(b1 & lt) : r2 + __popcll(b2 & lt));
+                    const uint32_t pos = (e & MP_POS_MASK) - k;
+                    if (MCHK(slot >= 1 && (uint32_t)slot < N, 11, slot, e)) {
+                        sa[slot] = (int)pos;
+                        if (pos < (uint32_t)HEAD) rk[pos] = slot;  // (all of the inverse array that the match kernels read)
+                    }
+                }
+                r0 += __popcll(b0);
+                r1 += __popcll(b1);
+                r2 += __popcll(b2);
+                const bool kp = valid && ell > k;
+                const uint64_t kb = __ballot(kp);
+                __builtin_amdgcn_wave_barrier();
+                if (kp) buf[keep + (uint32_t)__popcll(kb & lt)] = e;   // (behind every entry still to be read)
+                __builtin_amdgcn_wave_barrier();
+                keep += (uint32_t)__popcll(kb);
+            }
+            if (lane == 0) {
+                run[k] = r0;
+                run[256 + k] = r1;
+                run[255] = r2;
+            }
+            __builtin_amdgcn_wave_barrier();
+            cur = keep;
+        }
+    }
+}
+
+// A section of at most 4 x 64 entries whose chunks are shorter than 64 bytes, by one wave without tables: the entries stay
+// in registers (entry q * 64 + lane of the section: rank order), lane k holds the counts and then the first slots of
+// level k, the levels' records are placed by ballots.  Returns false (nothing written) when a chunk is too long.
+__device__ inline bool xp_small(const uint32_t *ent, uint32_t a, uint32_t cnt, int s0, int32_t *sa, int32_t *rk, int lane, uint32_t N) {
+    (void)N;
+    const uint64_t lt = lanemask_lt(lane);
+    uint32_t e[4];
+    bool v[4];
+    int mx = 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t x = (uint32_t)q * 64 + (uint32_t)lane;
+        v[q] = x < cnt;
+        e[q] = v[q] ? ent[a + x] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ell = (int)((e[q] >> 20) & 0xFFu);
+        mx = ell > mx ? ell : mx;
+    }
+    const int kmax = wave_max(mx);
+    if (kmax > 63) return false;
+    int cS = 0, cL = 0;  // lane k: entries of level k by type
+    int cD = 0;
+    for (int k = 1; k <= kmax; ++k) {
+        int s = 0, l = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t ty = e[q] >> 28;
+            const bool in = v[q] && (int)((e[q] >> 20) & 0xFFu) >= k;
+            s += __popcll(__ballot(in && ty == 0u));
+            l += __popcll(__ballot(in && ty == 1u));
+            if (k == 1) cD += __popcll(__ballot(in && ty == 2u));
+        }
+        if (lane == k) {
+            cS = s;
+            cL = l;
+        }
+    }
+    // first slots: levels 1 .. of the first type ascending, the deep bytes, the levels of the second type descending
+    const int iS = wave_incl_add(cS, lane), iL = wave_incl_add(cL, lane);
+    const int offD = s0 + lane_value(iS, 63);
+    const int oS = s0 + iS - cS;
+    const int oL = offD + cD + lane_value(iL, 63) - iL;
+    int rD = offD;
+    for (int k = 1; k <= kmax; ++k) {
+        int rS = lane_value(oS, k), rL = lane_value(oL, k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t ty = e[q] >> 28;
+            const bool in = v[q] && (int)((e[q] >> 20) & 0xFFu) >= k;
+            const uint64_t b0 = __ballot(in && ty == 0u), b1 = __ballot(in && ty == 1u), b2 = __ballot(in && ty == 2u);
+            if (in) {
+                const int slot = ty == 0u ? rS + __popcll(b0 & lt) : (ty == 1u ? rL + __popcll(b1 & lt) : rD + __popcll(b2 & lt));
+                const uint32_t pos = (e[q] & MP_POS_MASK) - (uint32_t)k;
+                if (MCHK(slot >= 1 && (uint32_t)slot < N && pos < N, 12, slot, e[q])) {
+                    sa[slot] = (int)pos;
+                    if (pos < (uint32_t)HEAD) rk[pos] = slot;
+                }
+            }
+            rS += __popcll(b0);
+            rL += __popcll(b1);
+            rD += __popcll(b2);
+        }
+    }
+    return true;
+}
+
+template <int DB>
+__global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM_WAVES * SA_WGS_PER_CU / 4, SAM_WAVES * SA_WGS_PER_CU / 4))) void sa_meta_kernel(const Seg *segs, const uint8_t *text, SaWork wk, int max_rounds) {
+    constexpr int NB = 1 << DB;
+    static_assert(SaInit<DB>::DIGITS == 4 && SaInit<DB>::SHIFT == 20, "keys of two 18-bit symbols");
+    static_assert(isa_binned<DB>(), "the expansion stores the ranks through the chunk streams");
+    static_assert(SAM_THREADS == 512 && NB >= XP_TAB, "level tables: one entry per thread");
+    __shared__ SaCarry cy;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+    const Seg sg = segs[blockIdx.x];
+    const uint8_t *T = text + sg.off;
+    const uint32_t n = sg.n;
+    const uint32_t N = n + 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int32_t *sa = wk.sa + sg.off, *rk = wk.isa + sg.off;
+    uint32_t *mpos = wk.mpos + sg.off;
+    uint32_t *pairs = wk.pairs + sg.off;
+
+    if (N == 1) {
+        if (tid == 0) {
+            sa[0] = 0;
+            rk[0] = 0;
+        }
+        return;
+    }
+    MPH_DECL
+    const uint32_t words = sa_bitmap_words<DB>(N);
+    const SaLds<DB> L(dyn_lds, words);
+    uint64_t *recA = wk.recA + sg.off, *recB = wk.recB + sg.off;
+
+    if (tid < 8) cy.fin_cnt[tid] = 0;
+    if (tid < 64) cy.bin_cur[tid] = 0;
+    for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;
+    for (int x = tid; x < 7 * NB; x += SAM_THREADS) L.base[x] = 0;  // base, delta, tpos, hl, hh, hy, hsec
+    for (int x = tid; x < SAM_WAVES * NB; x += SAM_THREADS) L.whist[x] = 0;
+    if (SA_MTAB)
+        for (int x = tid; x < SAM_WAVES * SaLds<DB>::mtab_entries(); x += SAM_THREADS) L.mtab[x] = 0;
+    __syncthreads();
+    MPH(0)
+
+    // ---- sweep: run lengths (rlen) and the items, every wave over a contiguous range of 64-position blocks.  A wave
+    //      appends its items (symbol << 32 | position) in text order to its own stretch of recA.
+    int32_t *hY = (int32_t *)L.act, *hX = hY + NB, *hC = L.hl, *hS = L.hh;  // act is free until the first regroup
+    const uint32_t nblk = (N + 63) / 64, per = (nblk + SAM_WAVES - 1) / SAM_WAVES;
+    {
+        const uint32_t wu = (uint32_t)wave_index(tid);
+        const uint32_t bb = wu * per, be = bb + per < nblk ? bb + per : nblk;
+        constexpr int PD = SA_SWEEP_AHEAD;
+        auto raw_load = [&](uint32_t blk) -> uint32_t {
+            const uint32_t q = blk * 64 + (uint32_t)lane;
+            uint16_t v = 0;
+            if (q < N) __builtin_memcpy(&v, T + q, 2);  // (zero padding follows the text)
+            return v;
+        };
+        auto flags_of = [&](uint32_t blk, uint32_t v) -> uint64_t {
+            const uint32_t q = blk * 64 + (uint32_t)lane;
+            return __ballot(q + 1 < n && (v & 0xFFu) == (v >> 8));
+        };
+        uint64_t *stage = recA + (uint64_t)bb * 64;
+        uint32_t cntw = 0;
+        uint64_t E1 = 0, E2 = 0, E3 = 0, E4 = 0, Eprev = 0;
+        uint32_t rawA = 0, rawB = 0;
+        if (bb < be) {
+            const uint32_t r0 = raw_load(bb), r1 = raw_load(bb + 1), r2 = raw_load(bb + 2), r3 = raw_load(bb + 3);
+            rawA = raw_load(bb + 4);
+            rawB = raw_load(bb + 5);
+            E1 = flags_of(bb, r0);
+            E2 = flags_of(bb + 1, r1);
+            E3 = flags_of(bb + 2, r2);
+            E4 = flags_of(bb + 3, r3);
+            if (bb > 0) {  // is the position before the wave's first equal to it?  (bit 63 of the block before)
+                const uint32_t q = bb * 64 - 1;
+                if (q + 1 < n && T[q] == T[q + 1]) Eprev = 1ull << 63;
+            }
+        }
+        int p_rl[PD];
+        uint32_t p_v[PD], p_s[PD];
+        bool p_it[PD];
+#pragma unroll
+        for (int t = 0; t < PD; ++t) {
+            p_rl[t] = 1;
+            p_v[t] = p_s[t] = 0;
+            p_it[t] = false;
+        }
+        for (uint32_t c = bb; c < be + PD && bb < be; ++c) {
+            int n_rl = 1;
+            uint32_t n_v = 0, n_s = 0;
+            bool n_it = false;
+            if (c < be) {
+                const uint64_t E0 = E1;
+                E1 = E2; E2 = E3; E3 = E4;
+                E4 = flags_of(c + 4, rawA);
+                rawA = rawB;
+                rawB = raw_load(c + 6);
+                const uint32_t e = c * 64 + (uint32_t)lane;
+                const uint64_t x0 = E0 >> lane;
+                int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);
+                if (rl == 64 - lane) {
+                    const uint64_t Et[4] = {E1, E2, E3, E4};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int rt = Et[t] == ~0ull ? 64 : (int)__builtin_ctzll(~Et[t]);
+                        rl += rt;
+                        if (rt < 64) break;
+                    }
+                }
+                n_rl = rl + 1;  // exact up to 257
+                // an item: the first position of its run (the flag of the position before is clear), or at least 253
+                // bytes of the run to go
+                const bool prev_eq = lane == 0 ? (Eprev >> 63) != 0 : ((E0 >> (lane - 1)) & 1ull) != 0;
+                Eprev = E0;
+                n_it = e < N && (!prev_eq || n_rl >= SA_RUN_CAP - 1);
+                if (e < N) {
+                    n_s = T[e];
+                    if (n_it && n_rl < SA_RUN_CAP) n_v = T[e + (uint32_t)n_rl];  // (the text is zero padded)
+                }
+            }
+            if (c >= bb + PD) {
+                const uint32_t e = (c - PD) * 64 + (uint32_t)lane;
+                const int rl = p_rl[0];
+                const bool valid = e < N;
+                if (valid) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
+                uint32_t sym = 0;  // the sentinel's
+                if (valid && e < n) {
+                    const uint32_t dS = p_s[0] + 1u;
+                    uint32_t dC = 255u;
+                    if (rl < SA_RUN_CAP) {
+                        const uint32_t q = e + (uint32_t)rl;
+                        const uint32_t dX = q < n ? p_v[0] + 1u : 0u;
+                        dC = dX < dS ? (uint32_t)rl : (uint32_t)(511 - rl);
+                    }
+                    sym = (dS << 9) | dC;
+                }
+                const bool it = p_it[0];
+                const uint64_t bm = __ballot(it);
+                if (it) stage[cntw + (uint32_t)__popcll(bm & lanemask_lt(lane))] = ((uint64_t)sym << 32) | (uint64_t)e;
+                cntw += (uint32_t)__popcll(bm);
+            }
+#pragma unroll
+            for (int t = 0; t + 1 < PD; ++t) {
+                p_rl[t] = p_rl[t + 1];
+                p_v[t] = p_v[t + 1];
+                p_s[t] = p_s[t + 1];
+                p_it[t] = p_it[t + 1];
+            }
+            p_rl[PD - 1] = n_rl;
+            p_v[PD - 1] = n_v;
+            p_s[PD - 1] = n_s;
+            p_it[PD - 1] = n_it;
+        }
+        if (lane == 0) cy.wcount[w] = (int32_t)cntw;
+    }
+    __syncthreads();
+    MPH(1)
+
+    // ---- the items get their index (text order), their position word and their record: key = the item's symbol and the
+    //      next item's (36 bits) << 20 | index; the digits of the keys are counted for the four passes
+    uint32_t base_w = 0, NM = 0;
+    for (int ww = 0; ww < SAM_WAVES; ++ww) {
+        const uint32_t c = (uint32_t)cy.wcount[ww];
+        if (ww < w) base_w += c;
+        NM += c;
+    }
+    {
+        const uint32_t wu = (uint32_t)wave_index(tid);
+        const uint64_t *stage = recA + (uint64_t)wu * per * 64;
+        const uint32_t cntw = (uint32_t)cy.wcount[wu];
+        uint64_t wnext = 0;  // the first item behind this wave's last one (none: the last item is the sentinel)
+        for (uint32_t ww = wu + 1; ww < (uint32_t)SAM_WAVES; ++ww)
+            if (cy.wcount[ww] > 0) {
+                wnext = recA[(uint64_t)ww * per * 64];
+                break;
+            }
+        for (uint32_t j00 = 0; j00 < cntw; j00 += 256) {  // four steps' loads in flight (a step alone waited a memory latency)
+            uint64_t itq[4], scq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t j = j00 + (uint32_t)q * 64 + (uint32_t)lane;
+                itq[q] = j < cntw ? stage[j] : 0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t jn = j00 + (uint32_t)(q + 1) * 64;
+                scq[q] = q < 3 ? lane_value(itq[q < 3 ? q + 1 : q], 0) : (jn < cntw ? stage[jn] : wnext);
+                if (jn >= cntw) scq[q] = wnext;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t j0 = j00 + (uint32_t)q * 64;
+                if (j0 >= cntw) break;
+                const uint32_t j = j0 + (uint32_t)lane;
+                const bool valid = j < cntw;
+                const uint64_t it = itq[q], succ = scq[q];
+                uint64_t nx;
+                {
+                    const uint32_t lo = (uint32_t)lane_above((int)(uint32_t)it, (int)(uint32_t)succ);
+                    const uint32_t hi = (uint32_t)lane_above((int)(uint32_t)(it >> 32), (int)(uint32_t)(succ >> 32));
+                    nx = (uint64_t)lo | ((uint64_t)hi << 32);
+                }
+                if (j + 1 == cntw) nx = wnext;
+                const uint32_t symA = (uint32_t)(it >> 32), e = (uint32_t)it, symB = (uint32_t)(nx >> 32);
+                const uint32_t i = base_w + j;
+                if (valid) {
+                    mpos[i] = e | ((((symA >> 9) - 1u) & 0xFFu) << MP_BYTE_SHIFT) | ((symA & 511u) == 255u ? 1u << MP_DEEP_SHIFT : 0u);
+                    recB[i] = ((((uint64_t)symA << 18) | (uint64_t)symB) << 20) | (uint64_t)i;
+                }
+                digit_count(hY, (int)(symB & 511u), valid, lane);
+                digit_count(hX, (int)(symB >> 9), valid, lane);
+                digit_count(hC, (int)(symA & 511u), valid, lane);
+                digit_count(hS, (int)(symA >> 9), valid, lane);
+            }
+        }
+    }
+    __syncthreads();
+    MPH(2)
+    // sections of the expansion: every item but the sentinel (digit 0) stands for one entry in the section of its byte
+    for (int x = tid; x < NB; x += SAM_THREADS) L.hsec[x] = x >= 1 ? hS[x] : 0;
+
+    // ---- the items' suffixes: initial order by the keys, regroup, small groups by direct comparison, doubling rounds
+    sa_initial_sort<DB>(L, recB, recA, NM, hY, hY, hX, hC, hS, tid);
+    MPH(3)
+    const uint64_t *rcur = recB;  // four passes
+    for (int x = tid; x < 2 * NB; x += SAM_THREADS) L.hl[x] = 0;  // hl, hh
+    for (uint32_t x = tid; x < words; x += SAM_THREADS) L.act[x] = 0;  // held two digit histograms so far
+    __syncthreads();
+    uint32_t m = sa_regroup<true, DB>(L, cy, rcur, NM, sa, rk, tid, (uint32_t *)recA, NM, pairs);
+    MPH(4)
+    m -= sa_finish<DB>(L, cy, (const uint32_t *)recA, NM, sa, rk, T, n, 2, tid, pairs, mpos);
+    MPH(5)
+    isa_flush<DB>(L, pairs, NM, rk, tid);
+    MPH(6)
+    sa_rounds<DB>(L, cy, recA, recB, sa, rk, NM, words, m, 2u, T, n, mpos, tid, max_rounds);
+    __syncthreads();
+    MPH(7)
+
+    // ---- expansion, pass P: in rank order, item u is the tail of the chunk before it (and, a deep byte, of itself): the
+    //      entries tail position | chunk length << 20 | type << 28 (0: the tail's byte is smaller than the chunk's, or the
+    //      text ends; 1: larger; 2: deep byte), scattered by the chunk's byte + 1; the bytes of every section are summed
+    const uint32_t m1 = NM - 1;            // entries: one per item but the sentinel (item m1)
+    uint32_t *ent = (uint32_t *)recA;
+    int32_t *secbytes = L.tpos;
+    for (int x = tid; x < NB; x += SAM_THREADS) secbytes[x] = 0;
+    if (tid == 0) cy.next_sec = 1;
+    __syncthreads();
+    bins_scan(L.hsec, L.base, NB, tid);
+    uint32_t un[SA_K];
+#pragma unroll
+    for (int s_ = 0; s_ < SA_K; ++s_) {
+        const uint32_t r = (uint32_t)w * SA_WSPAN + s_ * 64 + lane;
+        un[s_] = r < NM ? (uint32_t)sa[r] & 0x7FFFFFFFu : 0u;
+    }
+    for (uint32_t t0 = 0; t0 < NM; t0 += SA_TILE) {
+        const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
+        uint32_t ea[SA_K], eb[SA_K];
+        int da[SA_K], db[SA_K], la[SA_K], lb[SA_K];
+        bool va[SA_K], vb[SA_K];
+        uint32_t u[SA_K], w0[SA_K], w1[SA_K];
+#pragma unroll
+        for (int s_ = 0; s_ < SA_K; ++s_) {  // the position words of the item and of the item before it (all in flight)
+            const uint32_t r = wb + s_ * 64 + lane;
+            u[s_] = un[s_];
+            w0[s_] = 0;
+            w1[s_] = 0;
+            if (r < NM && MCHK(u[s_] < NM, 20, u[s_], r)) {
+                w1[s_] = mpos[u[s_]];
+                if (u[s_] >= 1) w0[s_] = mpos[u[s_] - 1];
+            }
+        }
+        if (t0 + SA_TILE < NM) {  // the next tile's ranks, loaded while this tile is placed
+#pragma unroll
+            for (int s_ = 0; s_ < SA_K; ++s_) {
+                const uint32_t r = wb + SA_TILE + s_ * 64 + lane;
+                un[s_] = r < NM ? (uint32_t)sa[r] & 0x7FFFFFFFu : 0u;
+            }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < SA_K; ++s_) {
+            const uint32_t r = wb + s_ * 64 + lane;
+            const bool ok = r < NM;
+            const uint32_t pos_u = w1[s_] & MP_POS_MASK, c_u = (w1[s_] >> MP_BYTE_SHIFT) & 0xFFu, c_p = (w0[s_] >> MP_BYTE_SHIFT) & 0xFFu;
+            const bool sentinel = u[s_] == m1;
+            va[s_] = ok && !sentinel && ((w1[s_] >> MP_DEEP_SHIFT) & 1u);
+            da[s_] = (int)c_u + 1;
+            ea[s_] = (pos_u + 1u) | (1u << 20) | (2u << 28);
+            vb[s_] = ok && u[s_] >= 1 && !((w0[s_] >> MP_DEEP_SHIFT) & 1u);
+            const uint32_t ell = pos_u - (w0[s_] & MP_POS_MASK);
+            db[s_] = (int)c_p + 1;
+            eb[s_] = pos_u | (ell << 20) | ((sentinel || c_u < c_p) ? 0u : 1u << 28);
+            lb[s_] = 0;
+            la[s_] = 0;
+            if (__ballot(vb[s_])) lb[s_] = tile_rank<9, DB>(L, w, db[s_], vb[s_], lane);
+            if (__ballot(va[s_])) la[s_] = tile_rank<9, DB>(L, w, da[s_], va[s_], lane);
+            if (vb[s_]) atomicAdd(&secbytes[db[s_]], (int)ell);
+            if (va[s_]) atomicAdd(&secbytes[da[s_]], 1);
+        }
+        tile_prepare<DB>(L, tid);
+#pragma unroll
+        for (int s_ = 0; s_ < SA_K; ++s_) {
+            if (vb[s_]) {
+                const int at = L.delta[db[s_]] + (int)L.woff[SaLds<DB>::cell(db[s_], w)] + lb[s_];
+                if (MCHK(at >= 0 && (uint32_t)at < m1, 21, at, eb[s_])) ent[at] = eb[s_];
+            }
+            if (va[s_]) {
+                const int at = L.delta[da[s_]] + (int)L.woff[SaLds<DB>::cell(da[s_], w)] + la[s_];
+                if (MCHK(at >= 0 && (uint32_t)at < m1, 22, at, ea[s_])) ent[at] = ea[s_];
+            }
+        }
+    }
+    __syncthreads();
+    MPH(8)
+    // L.base[d] is now the END of section d's entries; the sections' first slots: 1 + the bytes of the sections before
+    bins_scan(secbytes, L.delta, NB, tid);
+
+    // ---- expansion, pass X.  Scratch: the scatter tables (whist, woff, the peer table: 48 KiB, idle from here on) hold
+    //      the level tables of a section expanded by all waves (sh[wave][XP_TAB]) and, per wave, a table of its own and
+    //      its list of XP_W entries
+    int32_t *sh = (int32_t *)L.whist;
+    int32_t *run = sh + SAM_WAVES * XP_TAB + w * (XP_TAB + XP_W);
+    uint32_t *buf = (uint32_t *)(run + XP_TAB);
+    int32_t *tot = L.hl;   // [XP_TAB] (hl, hh: idle)
+    if (tid == 0) {
+        sa[0] = (int)n;
+        if (n < (uint32_t)HEAD) rk[n] = 0;
+    }
+    MPH(9)
+    // large sections: every wave a slice
+    for (int d = 1; d <= 256; ++d) {
+        const uint32_t cnt = (uint32_t)L.hsec[d];
+        if (cnt < XP_BIG) continue;
+        const uint32_t a0 = (uint32_t)L.base[d] - cnt;
+        const uint32_t pw = ((cnt + SAM_WAVES - 1) / SAM_WAVES + 63u) & ~63u;
+        const uint32_t a = a0 + min((uint32_t)w * pw, cnt), b = a0 + min((uint32_t)(w + 1) * pw, cnt);
+        int32_t *mine = sh + w * XP_TAB;
+        for (int x = lane; x < XP_TAB; x += 64) mine[x] = 0;
+        __builtin_amdgcn_wave_barrier();
+        (void)xp_count(ent, a, b, mine, lane);
+        xp_levels(mine, lane, 3);
+        __syncthreads();
+        {   // per level: the waves' counts -> their offsets inside the level, and the level's total
+            int r = 0;
+            for (int ww = 0; ww < SAM_WAVES; ++ww) {
+                const int c = sh[ww * XP_TAB + tid];
+                sh[ww * XP_TAB + tid] = r;
+                r += c;
+            }
+            tot[tid] = r;
+        }
+        __syncthreads();
+        if (w == 0) xp_offsets(tot, tot, 1 + L.delta[d], lane, 3);
+        __syncthreads();
+        for (int x = lane; x < XP_TAB; x += 64) run[x] = tot[x] + mine[x];
+        __builtin_amdgcn_wave_barrier();
+        xp_expand(ent, a, b, run, buf, sa, rk, lane, N);
+        __syncthreads();
+    }
+    MPH(10)
+    // the other sections: a wave takes the next one when it is free
+    for (;;) {
+        int d = 0;
+        if (lane == 0) d = atomicAdd(&cy.next_sec, 1);
+        d = lane_value(d, 0);
+        if (d > 256) break;
+        const uint32_t cnt = (uint32_t)L.hsec[d];
+        if (cnt == 0 || cnt >= XP_BIG) continue;
+        const uint32_t a = (uint32_t)L.base[d] - cnt, b = a + cnt;
+        if (cnt <= 256u && xp_small(ent, a, cnt, 1 + L.delta[d], sa, rk, lane, N)) continue;
+        for (int x = lane; x < XP_TAB; x += 64) run[x] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const int qmax = xp_count(ent, a, b, run, lane) >> 6;
+        xp_levels(run, lane, qmax);
+        xp_offsets(run, run, 1 + L.delta[d], lane, qmax);
+        xp_expand(ent, a, b, run, buf, sa, rk, lane, N);
+    }
+    MPH(11)
+    // (no inverse array: the items' ranks have used its buffer, and nothing behind the suffix sort reads more of it than
+    // the ranks of the first HEAD positions, stored above; launch_isa_from_sa fills it for the index views of the tests)
+    MPH_PRINT
 }
 
 // ---- window index: ranks regrouped by the 16 KiB chunk of their position (stable in rank order) ------
@@ -1388,6 +2031,19 @@ __global__ __launch_bounds__(256) void block64_kernel(const Seg *segs, const int
     if ((threadIdx.x & 63) == 0) out[sg.off / 64 + (j >> 6)] = v;
 }
 
+// The inverse suffix array of whole segments, isa[sa[k]] = k.  The run-compressed sort leaves only the ranks of the first
+// HEAD positions behind (all that the match kernels read); the index views of the C ABI (mi355_lzss_batch_index,
+// tests) call this for the segment they hand out.
+__global__ __launch_bounds__(256) void isa_from_sa_kernel(const Seg *segs, const int32_t *sa, int32_t *isa) {
+    const Seg sg = segs[blockIdx.y];
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k <= sg.n) isa[sg.off + (uint32_t)sa[sg.off + k]] = (int32_t)k;
+}
+void launch_isa_from_sa(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const int32_t *d_sa, int32_t *d_isa, hipStream_t stream) {
+    if (n_segs == 0) return;
+    hipLaunchKernelGGL(isa_from_sa_kernel, dim3((max_n + 256) / 256, n_segs), dim3(256), 0, stream, d_segs, d_sa, d_isa);
+}
+
 void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream) {
     if (n_segs == 0 || max_n == 0) return;
     hipLaunchKernelGGL(window_index_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, ix);
@@ -1415,7 +2071,26 @@ static void launch_sa_small(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, 
                                   (int)SaLds<9>::bytes(sa_bitmap_words<9>(1u << 18)));
         (void)hipFuncSetAttribute((const void *)sa_build_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)SaLds<10>::bytes(sa_bitmap_words<10>(SA_BITMAP_MAX_N)));
+        (void)hipFuncSetAttribute((const void *)sa_meta_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)SaLds<9>::bytes(sa_bitmap_words<9>(1u << 18)));
+        (void)hipFuncSetAttribute((const void *)sa_meta_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)SaLds<10>::bytes(sa_bitmap_words<10>(SA_BITMAP_MAX_N)));
         attr_devs.fetch_or(dbit, std::memory_order_release);
+    }
+#ifdef LZSS_DEBUG_KNOBS
+    static const bool plain = getenv("MI355_LZSS_SA_PLAIN") != nullptr;  // the sort of every suffix, for comparisons
+#else
+    constexpr bool plain = false;
+#endif
+    if (SA_META && wk.mpos && !plain) {  // run-compressed sort
+        if (N <= (1u << 18)) {
+            hipLaunchKernelGGL(sa_meta_kernel<9>, dim3(n_segs), dim3(SAM_THREADS), SaLds<9>::bytes(sa_bitmap_words<9>(N)), stream,
+                               d_segs, d_text, wk, max_rounds);
+        } else {
+            hipLaunchKernelGGL(sa_meta_kernel<10>, dim3(n_segs), dim3(SAM_THREADS), SaLds<10>::bytes(sa_bitmap_words<10>(N)), stream,
+                               d_segs, d_text, wk, max_rounds);
+        }
+        return;
     }
     if (N <= (1u << 18)) {
         hipLaunchKernelGGL(sa_build_kernel<9>, dim3(n_segs), dim3(SAM_THREADS), SaLds<9>::bytes(sa_bitmap_words<9>(N)), stream,
