@@ -1333,23 +1333,23 @@ __device__ int g_meta_bad = 0;
 #define MPH_PRINT
 #endif
 constexpr int XP_W = 512;            // entries a wave expands at a time (its private list in LDS)
-constexpr uint32_t XP_BIG = 4096;    // sections of at least this many entries are expanded by all waves together
+constexpr uint32_t XP_BIG = 1024;    // sections of at least this many entries are expanded by all waves together
 constexpr int XP_TAB = 512;          // level table: [k] chunks followed by a smaller byte, [255] deep bytes, [256 + k] by a larger one
 
-// histogram of (type, chunk length) of entries [a, b) into tab (zeroed); one wave.  Returns the largest chunk length.
+// histogram of (type, level count) of entries [a, b) into tab (zeroed); one wave.  Returns the largest level count.
 __device__ inline int xp_count(const uint32_t *ent, uint32_t a, uint32_t b, int32_t *tab, int lane) {
     int mx = 1;
     for (uint32_t x = a + (uint32_t)lane; x < b; x += 64) {
         const uint32_t e = ent[x];
-        const uint32_t ty = e >> 28, ell = (e >> 20) & 0xFFu;
-        atomicAdd(&tab[ty == 2u ? 255u : (ty == 1u ? 256u + ell : ell)], 1);
+        const uint32_t ty = (e >> 28) & 1u, ell = (e >> 20) & 0xFFu;
+        atomicAdd(&tab[ty * 256u + ell], 1);
         mx = (int)ell > mx ? (int)ell : mx;
     }
     __builtin_amdgcn_wave_barrier();
     return wave_max(mx);
 }
-// tab[k] = number of entries of that type with chunk length >= k (in place, k = 1 .. 253 of both types); one wave.
-// qmax: no chunk is longer than 64 qmax + 63 (the 64-entry stretches of the tables above that are zero and stay so)
+// tab[k] = number of entries of that type with at least k levels (in place, k = 1 .. 253 of both types); one wave.
+// qmax: no entry has more than 64 qmax + 63 levels (the 64-entry stretches of the tables above that are zero and stay so)
 __device__ inline void xp_levels(int32_t *tab, int lane, int qmax) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -1366,10 +1366,13 @@ __device__ inline void xp_levels(int32_t *tab, int lane, int qmax) {
     }
     __builtin_amdgcn_wave_barrier();
 }
-// out[.] = first slot of every level's records in the section that starts at slot s0, from the section's level counts
-// cnt: run codes ascending - levels 1 .. 253 of the chunks followed by a smaller byte, the deep bytes, levels 253 .. 1 of
-// the chunks followed by a larger byte.  One wave; out may be cnt.
-__device__ inline void xp_offsets(const int32_t *cnt, int32_t *out, int s0, int lane, int qmax) {
+// out[.] = first slot of every level's records in the section that starts at slot s0 and holds secb bytes, from the
+// section's level counts cnt.  The suffixes of a section (first byte c) are ordered by the length of the run of c they
+// start with: runs followed by a smaller byte (or the end of the text) first, shorter ones first - levels 1, 2, ... of
+// type 0 ascending -, then runs followed by a larger byte, longer ones first - the levels of type 1 descending.  The
+// levels beyond 253 (runs longer than that, rare) sit between the two halves of the table: out[255] = their first slot,
+// out[254] = how many records they are (xp_long places them).  One wave; out may be cnt.
+__device__ inline void xp_offsets(const int32_t *cnt, int32_t *out, int s0, int secb, int lane, int qmax) {
     int c0[4], c1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1378,21 +1381,25 @@ __device__ inline void xp_offsets(const int32_t *cnt, int32_t *out, int s0, int 
         c0[q] = in ? cnt[idx] : 0;
         c1[q] = in ? cnt[256 + idx] : 0;
     }
-    const int deep = cnt[255];
     __builtin_amdgcn_wave_barrier();
-    int carry = s0;
+    int carry = s0, tot1 = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // smaller type: ascending k
+    for (int q = 0; q < 4; ++q) {  // type 0: ascending k
         if (q > qmax) continue;
         const int idx = q * 64 + lane;
         const int pre = wave_incl_add(c0[q], lane);
         if (idx >= 1 && idx <= 253) out[idx] = carry + pre - c0[q];
         carry += lane_value(pre, 63);
+        tot1 += lane_value(wave_incl_add(c1[q], lane), 63);
     }
-    if (lane == 0) out[255] = carry;
-    carry += deep;
+    const int nlong = secb - (carry - s0) - tot1;  // records of the levels beyond 253
+    if (lane == 0) {
+        out[255] = carry;
+        out[254] = nlong;
+    }
+    carry += nlong;
 #pragma unroll
-    for (int q = 3; q >= 0; --q) {  // larger type: descending k
+    for (int q = 3; q >= 0; --q) {  // type 1: descending k
         if (q > qmax) continue;
         const int idx = q * 64 + lane;
         const int pre = wave_incl_add(c1[q], lane);
@@ -1402,8 +1409,9 @@ __device__ inline void xp_offsets(const int32_t *cnt, int32_t *out, int s0, int 
     }
     __builtin_amdgcn_wave_barrier();
 }
-// Entries [a, b) of one section, level by level: level k writes the records of the entries with l >= k (run[] holds the
-// next free slot of every level and moves on), then drops the entries with l == k from the wave's list.  One wave.
+// Entries [a, b) of one section, level by level: level k writes the records of the entries with at least k levels (run[]
+// holds the next free slot of every level and moves on), then drops the entries with exactly k from the wave's list.
+// Four steps of 64 entries at a time, so that their LDS and global round trips overlap.  One wave.
 __device__ inline void xp_expand(const uint32_t *ent, uint32_t a, uint32_t b, int32_t *run, uint32_t *buf, int32_t *sa,
                                  int32_t *rk, int lane, uint32_t N) {
     (void)N;
@@ -1413,36 +1421,46 @@ __device__ inline void xp_expand(const uint32_t *ent, uint32_t a, uint32_t b, in
         for (uint32_t x = lane; x < cur; x += 64) buf[x] = ent[a0 + x];
         __builtin_amdgcn_wave_barrier();
         for (uint32_t k = 1; cur > 0; ++k) {
-            int r0 = run[k], r1 = run[256 + k], r2 = run[255];
+            int r0 = run[k], r1 = run[256 + k];
             uint32_t keep = 0;
-            for (uint32_t c0 = 0; c0 < cur; c0 += 64) {
-                const uint32_t x = c0 + (uint32_t)lane;
-                const bool valid = x < cur;
-                const uint32_t e = valid ? buf[x] : 0u;
-                const uint32_t ty = e >> 28, ell = (e >> 20) & 0xFFu;
-                const uint64_t b0 = __ballot(valid && ty == 0u), b1 = __ballot(valid && ty == 1u), b2 = __ballot(valid && ty == 2u);
-                if (valid && MCHK((e & MP_POS_MASK) >= k && (e & MP_POS_MASK) - k < N && ty <= 2u && k <= 253u, 10, e, k)) {
-                    const int slot = ty == 0u ? r0 + __popcll(b0 & lt) : (ty == 1u ? r1 + __popcll(b1 & lt) : r2 + __popcll(b2 & lt));
-                    const uint32_t pos = (e & MP_POS_MASK) - k;
-                    if (MCHK(slot >= 1 && (uint32_t)slot < N, 11, slot, e)) {
-                        sa[slot] = (int)pos;
-                        if (pos < (uint32_t)HEAD) rk[pos] = slot;  // (all of the inverse array that the match kernels read)
-                    }
+            for (uint32_t c0 = 0; c0 < cur; c0 += 256) {
+                uint32_t e[4];
+                bool kp[4];
+                uint64_t kb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t x = c0 + (uint32_t)q * 64 + (uint32_t)lane;
+                    e[q] = x < cur ? buf[x] : 0u;   // (a valid entry is never 0: it has at least one level)
                 }
-                r0 += __popcll(b0);
-                r1 += __popcll(b1);
-                r2 += __popcll(b2);
-                const bool kp = valid && ell > k;
-                const uint64_t kb = __ballot(kp);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool valid = e[q] != 0u;
+                    const uint32_t ty = (e[q] >> 28) & 1u, ell = (e[q] >> 20) & 0xFFu;
+                    const uint64_t b0 = __ballot(valid && ty == 0u), b1 = __ballot(valid && ty == 1u);
+                    if (valid && MCHK((e[q] & MP_POS_MASK) >= k && (e[q] & MP_POS_MASK) - k < N && k <= 253u, 10, e[q], k)) {
+                        const int slot = ty == 0u ? r0 + __popcll(b0 & lt) : r1 + __popcll(b1 & lt);
+                        const uint32_t pos = (e[q] & MP_POS_MASK) - k;
+                        if (MCHK(slot >= 1 && (uint32_t)slot < N, 11, slot, e[q])) {
+                            sa[slot] = (int)pos;
+                            if (pos < (uint32_t)HEAD) rk[pos] = slot;  // (all of the inverse array that the match kernels read)
+                        }
+                    }
+                    r0 += __popcll(b0);
+                    r1 += __popcll(b1);
+                    kp[q] = valid && ell > k;
+                    kb[q] = __ballot(kp[q]);
+                }
                 __builtin_amdgcn_wave_barrier();
-                if (kp) buf[keep + (uint32_t)__popcll(kb & lt)] = e;   // (behind every entry still to be read)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (kp[q]) buf[keep + (uint32_t)__popcll(kb[q] & lt)] = e[q];   // (in front of every entry still to be read)
+                    keep += (uint32_t)__popcll(kb[q]);
+                }
                 __builtin_amdgcn_wave_barrier();
-                keep += (uint32_t)__popcll(kb);
             }
             if (lane == 0) {
                 run[k] = r0;
                 run[256 + k] = r1;
-                run[255] = r2;
             }
             __builtin_amdgcn_wave_barrier();
             cur = keep;
@@ -1450,9 +1468,9 @@ __device__ inline void xp_expand(const uint32_t *ent, uint32_t a, uint32_t b, in
     }
 }
 
-// A section of at most 4 x 64 entries whose chunks are shorter than 64 bytes, by one wave without tables: the entries stay
-// in registers (entry q * 64 + lane of the section: rank order), lane k holds the counts and then the first slots of
-// level k, the levels' records are placed by ballots.  Returns false (nothing written) when a chunk is too long.
+// A section of at most 4 x 64 entries with fewer than 64 levels each, by one wave without tables: the entries stay in
+// registers (entry q * 64 + lane of the section: rank order), lane k holds the counts and then the first slots of level
+// k, the levels' records are placed by ballots.  Returns false (nothing written) when an entry has too many levels.
 __device__ inline bool xp_small(const uint32_t *ent, uint32_t a, uint32_t cnt, int s0, int32_t *sa, int32_t *rk, int lane, uint32_t N) {
     (void)N;
     const uint64_t lt = lanemask_lt(lane);
@@ -1473,37 +1491,33 @@ __device__ inline bool xp_small(const uint32_t *ent, uint32_t a, uint32_t cnt, i
     const int kmax = wave_max(mx);
     if (kmax > 63) return false;
     int cS = 0, cL = 0;  // lane k: entries of level k by type
-    int cD = 0;
     for (int k = 1; k <= kmax; ++k) {
         int s = 0, l = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t ty = e[q] >> 28;
+            const uint32_t ty = (e[q] >> 28) & 1u;
             const bool in = v[q] && (int)((e[q] >> 20) & 0xFFu) >= k;
             s += __popcll(__ballot(in && ty == 0u));
             l += __popcll(__ballot(in && ty == 1u));
-            if (k == 1) cD += __popcll(__ballot(in && ty == 2u));
         }
         if (lane == k) {
             cS = s;
             cL = l;
         }
     }
-    // first slots: levels 1 .. of the first type ascending, the deep bytes, the levels of the second type descending
+    // first slots: the levels of type 0 ascending, then the levels of type 1 descending
     const int iS = wave_incl_add(cS, lane), iL = wave_incl_add(cL, lane);
-    const int offD = s0 + lane_value(iS, 63);
     const int oS = s0 + iS - cS;
-    const int oL = offD + cD + lane_value(iL, 63) - iL;
-    int rD = offD;
+    const int oL = s0 + lane_value(iS, 63) + lane_value(iL, 63) - iL;
     for (int k = 1; k <= kmax; ++k) {
         int rS = lane_value(oS, k), rL = lane_value(oL, k);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t ty = e[q] >> 28;
+            const uint32_t ty = (e[q] >> 28) & 1u;
             const bool in = v[q] && (int)((e[q] >> 20) & 0xFFu) >= k;
-            const uint64_t b0 = __ballot(in && ty == 0u), b1 = __ballot(in && ty == 1u), b2 = __ballot(in && ty == 2u);
+            const uint64_t b0 = __ballot(in && ty == 0u), b1 = __ballot(in && ty == 1u);
             if (in) {
-                const int slot = ty == 0u ? rS + __popcll(b0 & lt) : (ty == 1u ? rL + __popcll(b1 & lt) : rD + __popcll(b2 & lt));
+                const int slot = ty == 0u ? rS + __popcll(b0 & lt) : rL + __popcll(b1 & lt);
                 const uint32_t pos = (e[q] & MP_POS_MASK) - (uint32_t)k;
                 if (MCHK(slot >= 1 && (uint32_t)slot < N && pos < N, 12, slot, e[q])) {
                     sa[slot] = (int)pos;
@@ -1512,10 +1526,84 @@ __device__ inline bool xp_small(const uint32_t *ent, uint32_t a, uint32_t cnt, i
             }
             rS += __popcll(b0);
             rL += __popcll(b1);
-            rD += __popcll(b2);
         }
     }
     return true;
+}
+
+// The levels beyond 253 of a section: its long runs (entries with the long bit, their lengths in runlen[tail]) in rank
+// order, nlong records from slot `first` on - levels 254, 255, ... of the runs of type 0 ascending, then the levels of
+// the runs of type 1 descending.  The long entries are first listed (tail << 32 | length << 1 | type, in `list`, which has
+// room for one word per entry of the section); then 64 levels at a time, lane l the level k0 + l: a pass over the list
+// counts every level's records, a second one places them.  One wave.
+__device__ inline void xp_long(const uint32_t *ent, uint32_t a, uint32_t b, const uint32_t *runlen, uint64_t *list, int first,
+                               int nlong, int32_t *sa, int32_t *rk, int lane, uint32_t N) {
+    (void)N;
+    (void)nlong;
+    const uint64_t lt = lanemask_lt(lane);
+    uint32_t J = 0;
+    for (uint32_t x0 = a; x0 < b; x0 += 64) {
+        const uint32_t x = x0 + (uint32_t)lane;
+        const uint32_t e = x < b ? ent[x] : 0u;
+        const bool lg = (e >> 30) & 1u;
+        const uint64_t bm = __ballot(lg);
+        if (lg) list[J + (uint32_t)__popcll(bm & lt)] = ((uint64_t)(e & MP_POS_MASK) << 32) | ((uint64_t)runlen[e & MP_POS_MASK] << 1) | (uint64_t)((e >> 28) & 1u);
+        J += (uint32_t)__popcll(bm);
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // the list is read back below (by this wave)
+    __builtin_amdgcn_wave_barrier();
+    // totals per type and the longest run
+    uint32_t tS = 0, tL = 0, lmax = 0;
+    for (uint32_t j0 = 0; j0 < J; j0 += 64) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        const uint64_t it = j < J ? list[j] : 0ull;
+        const uint32_t len = (uint32_t)(it >> 1) & 0x7FFFFFFFu;
+        const uint32_t extra = j < J ? len - (uint32_t)(SA_RUN_CAP - 1) : 0u;
+        tS += (uint32_t)lane_value(wave_incl_add((it & 1ull) ? 0 : (int)extra, lane), 63);
+        tL += (uint32_t)lane_value(wave_incl_add((it & 1ull) ? (int)extra : 0, lane), 63);
+        lmax = (uint32_t)wave_max((int)len) > lmax ? (uint32_t)wave_max((int)len) : lmax;
+    }
+    uint32_t fS = 0, pL = 0;  // records of type 0 in the levels below the block; of type 1
+    for (uint32_t k0 = (uint32_t)SA_RUN_CAP; k0 <= lmax; k0 += 64) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        int cS = 0, cL = 0;
+        for (uint32_t j0 = 0; j0 < J; j0 += 64) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const uint64_t it = j < J ? list[j] : 0ull;
+            const int len = (int)((uint32_t)(it >> 1) & 0x7FFFFFFFu), ty = (int)(it & 1ull);
+            const int nn = (int)(J - j0 < 64u ? J - j0 : 64u);
+            for (int i = 0; i < nn; ++i) {
+                const bool in = (uint32_t)lane_value(len, i) >= k;
+                if (lane_value(ty, i)) cL += in ? 1 : 0;
+                else cS += in ? 1 : 0;
+            }
+        }
+        const int iS = wave_incl_add(cS, lane), iL = wave_incl_add(cL, lane);
+        int rS = first + (int)fS + iS - cS;                         // the levels below k of type 0 come first
+        int rL = first + (int)tS + (int)tL - (int)pL - iL;            // the levels above k of type 1 come first
+        for (uint32_t j0 = 0; j0 < J; j0 += 64) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const uint64_t it = j < J ? list[j] : 0ull;
+            const int len = (int)((uint32_t)(it >> 1) & 0x7FFFFFFFu), ty = (int)(it & 1ull), tail = (int)(it >> 32);
+            const int nn = (int)(J - j0 < 64u ? J - j0 : 64u);
+            for (int i = 0; i < nn; ++i) {
+                const bool in = (uint32_t)lane_value(len, i) >= k;
+                const int t_ = lane_value(ty, i);
+                const uint32_t pos = (uint32_t)lane_value(tail, i) - k;
+                if (in) {
+                    const int slot = t_ ? rL : rS;
+                    if (MCHK(slot >= 1 && (uint32_t)slot < N && pos < N, 13, slot, pos)) {
+                        sa[slot] = (int)pos;
+                        if (pos < (uint32_t)HEAD) rk[pos] = slot;
+                    }
+                    if (t_) ++rL;
+                    else ++rS;
+                }
+            }
+        }
+        fS += (uint32_t)lane_value(iS, 63);
+        pL += (uint32_t)lane_value(iL, 63);
+    }
 }
 
 template <int DB>
@@ -1564,7 +1652,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     {
         const uint32_t wu = (uint32_t)wave_index(tid);
         const uint32_t bb = wu * per, be = bb + per < nblk ? bb + per : nblk;
-        constexpr int PD = SA_SWEEP_AHEAD;
+        constexpr int G = 4;  // blocks per step: their scattered loads are in flight together (a block alone waited a latency)
         auto raw_load = [&](uint32_t blk) -> uint32_t {
             const uint32_t q = blk * 64 + (uint32_t)lane;
             uint16_t v = 0;
@@ -1577,95 +1665,99 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         };
         uint64_t *stage = recA + (uint64_t)bb * 64;
         uint32_t cntw = 0;
-        uint64_t E1 = 0, E2 = 0, E3 = 0, E4 = 0, Eprev = 0;
-        uint32_t rawA = 0, rawB = 0;
         if (bb < be) {
-            const uint32_t r0 = raw_load(bb), r1 = raw_load(bb + 1), r2 = raw_load(bb + 2), r3 = raw_load(bb + 3);
-            rawA = raw_load(bb + 4);
-            rawB = raw_load(bb + 5);
-            E1 = flags_of(bb, r0);
-            E2 = flags_of(bb + 1, r1);
-            E3 = flags_of(bb + 2, r2);
-            E4 = flags_of(bb + 3, r3);
-            if (bb > 0) {  // is the position before the wave's first equal to it?  (bit 63 of the block before)
-                const uint32_t q = bb * 64 - 1;
-                if (q + 1 < n && T[q] == T[q + 1]) Eprev = 1ull << 63;
+            // the position before the wave's first: is it equal to it, and how far is it from the first byte of its run
+            uint32_t dcar = 0;
+            bool eqcar = false;
+            if (bb > 0) {
+                const uint32_t q0 = bb * 64 - 1;
+                eqcar = q0 + 1 < n && T[q0] == T[q0 + 1];
+                for (uint32_t q = q0;;) {  // lane l: is position q - l equal to the one before it?
+                    const bool eq = q >= (uint32_t)lane + 1 && T[q - (uint32_t)lane - 1] == T[q - (uint32_t)lane];
+                    const uint64_t bm = __ballot(eq);
+                    const int c = bm == ~0ull ? 64 : (int)__builtin_ctzll(~bm);
+                    dcar += (uint32_t)c;
+                    if (c < 64 || q < 64) break;
+                    q -= 64;
+                }
             }
-        }
-        int p_rl[PD];
-        uint32_t p_v[PD], p_s[PD];
-        bool p_it[PD];
+            const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+            uint32_t rw[2 * G], rn[G];
+            uint64_t E[2 * G];
 #pragma unroll
-        for (int t = 0; t < PD; ++t) {
-            p_rl[t] = 1;
-            p_v[t] = p_s[t] = 0;
-            p_it[t] = false;
-        }
-        for (uint32_t c = bb; c < be + PD && bb < be; ++c) {
-            int n_rl = 1;
-            uint32_t n_v = 0, n_s = 0;
-            bool n_it = false;
-            if (c < be) {
-                const uint64_t E0 = E1;
-                E1 = E2; E2 = E3; E3 = E4;
-                E4 = flags_of(c + 4, rawA);
-                rawA = rawB;
-                rawB = raw_load(c + 6);
-                const uint32_t e = c * 64 + (uint32_t)lane;
-                const uint64_t x0 = E0 >> lane;
-                int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);
-                if (rl == 64 - lane) {
-                    const uint64_t Et[4] = {E1, E2, E3, E4};
+            for (int i = 0; i < 2 * G; ++i) rw[i] = raw_load(bb + i);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int rt = Et[t] == ~0ull ? 64 : (int)__builtin_ctzll(~Et[t]);
-                        rl += rt;
-                        if (rt < 64) break;
+            for (int i = 0; i < G; ++i) rn[i] = raw_load(bb + 2 * G + i);
+#pragma unroll
+            for (int i = 0; i < 2 * G; ++i) E[i] = flags_of(bb + i, rw[i]);
+            for (uint32_t c = bb; c < be; c += G) {
+                int rl_[G];
+                bool it_[G];
+                uint32_t xv[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint32_t e = (c + g) * 64 + (uint32_t)lane;
+                    const uint64_t E0 = E[g];
+                    const uint64_t x0 = E0 >> lane;
+                    int rl = (x0 == ~0ull) ? 64 : (int)__builtin_ctzll(~x0);
+                    if (rl == 64 - lane) {
+#pragma unroll
+                        for (int t = 1; t <= 4; ++t) {
+                            const int rt = E[g + t] == ~0ull ? 64 : (int)__builtin_ctzll(~E[g + t]);
+                            rl += rt;
+                            if (rt < 64) break;
+                        }
                     }
+                    rl_[g] = rl + 1;  // exact up to 257
+                    // bytes of the run before this position: from the flags of the block, or carried over from the block before
+                    const uint64_t P = (E0 << 1) | (eqcar ? 1ull : 0ull);  // bit l: position e equals the one before it
+                    const uint64_t zl = ~P & le;
+                    const uint32_t d = zl ? (uint32_t)lane - (uint32_t)(63 - (int)__builtin_clzll(zl)) : dcar + 1u + (uint32_t)lane;
+                    dcar = (uint32_t)lane_value((int)d, 63);
+                    eqcar = (E0 >> 63) != 0;
+                    // an item: the first byte of a run and every 253rd byte behind it
+                    it_[g] = c + g < be && e < N && d % (uint32_t)(SA_RUN_CAP - 1) == 0u;
+                    xv[g] = 0;
+                    if (it_[g] && rl_[g] < SA_RUN_CAP) xv[g] = T[e + (uint32_t)rl_[g]];  // (the text is zero padded)
                 }
-                n_rl = rl + 1;  // exact up to 257
-                // an item: the first position of its run (the flag of the position before is clear), or at least 253
-                // bytes of the run to go
-                const bool prev_eq = lane == 0 ? (Eprev >> 63) != 0 : ((E0 >> (lane - 1)) & 1ull) != 0;
-                Eprev = E0;
-                n_it = e < N && (!prev_eq || n_rl >= SA_RUN_CAP - 1);
-                if (e < N) {
-                    n_s = T[e];
-                    if (n_it && n_rl < SA_RUN_CAP) n_v = T[e + (uint32_t)n_rl];  // (the text is zero padded)
-                }
-            }
-            if (c >= bb + PD) {
-                const uint32_t e = (c - PD) * 64 + (uint32_t)lane;
-                const int rl = p_rl[0];
-                const bool valid = e < N;
-                if (valid) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
-                uint32_t sym = 0;  // the sentinel's
-                if (valid && e < n) {
-                    const uint32_t dS = p_s[0] + 1u;
-                    uint32_t dC = 255u;
-                    if (rl < SA_RUN_CAP) {
-                        const uint32_t q = e + (uint32_t)rl;
-                        const uint32_t dX = q < n ? p_v[0] + 1u : 0u;
-                        dC = dX < dS ? (uint32_t)rl : (uint32_t)(511 - rl);
-                    }
-                    sym = (dS << 9) | dC;
-                }
-                const bool it = p_it[0];
-                const uint64_t bm = __ballot(it);
-                if (it) stage[cntw + (uint32_t)__popcll(bm & lanemask_lt(lane))] = ((uint64_t)sym << 32) | (uint64_t)e;
-                cntw += (uint32_t)__popcll(bm);
-            }
+                uint64_t En[G];
+                uint32_t rq[G];
 #pragma unroll
-            for (int t = 0; t + 1 < PD; ++t) {
-                p_rl[t] = p_rl[t + 1];
-                p_v[t] = p_v[t + 1];
-                p_s[t] = p_s[t + 1];
-                p_it[t] = p_it[t + 1];
+                for (int g = 0; g < G; ++g) {
+                    En[g] = flags_of(c + 2 * G + g, rn[g]);
+                    rq[g] = rn[g];
+                    rn[g] = raw_load(c + 3 * G + g);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (c + g >= be) break;
+                    const uint32_t e = (c + g) * 64 + (uint32_t)lane;
+                    const int rl = rl_[g];
+                    const bool valid = e < N;
+                    if (valid) wk.rlen[sg.off + e] = (uint8_t)(rl < 255 ? rl : 255);
+                    uint32_t sym = 0;  // the sentinel's
+                    if (valid && e < n) {
+                        const uint32_t dS = (rw[g] & 0xFFu) + 1u;
+                        uint32_t dC = 255u;  // 253 bytes of a run that goes on
+                        if (rl < SA_RUN_CAP) {
+                            const uint32_t q = e + (uint32_t)rl;
+                            const uint32_t dX = q < n ? xv[g] + 1u : 0u;
+                            dC = dX < dS ? (uint32_t)rl : (uint32_t)(511 - rl);
+                        }
+                        sym = (dS << 9) | dC;
+                    }
+                    const uint64_t bm = __ballot(it_[g]);
+                    if (it_[g]) stage[cntw + (uint32_t)__popcll(bm & lanemask_lt(lane))] = ((uint64_t)sym << 32) | (uint64_t)e;
+                    cntw += (uint32_t)__popcll(bm);
+                }
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    E[i] = E[G + i];
+                    rw[i] = rw[G + i];
+                    E[G + i] = En[i];
+                    rw[G + i] = rq[i];
+                }
             }
-            p_rl[PD - 1] = n_rl;
-            p_v[PD - 1] = n_v;
-            p_s[PD - 1] = n_s;
-            p_it[PD - 1] = n_it;
         }
         if (lane == 0) cy.wcount[w] = (int32_t)cntw;
     }
@@ -1727,13 +1819,13 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                 digit_count(hX, (int)(symB >> 9), valid, lane);
                 digit_count(hC, (int)(symA & 511u), valid, lane);
                 digit_count(hS, (int)(symA >> 9), valid, lane);
+                // sections of the expansion: one entry per run, in the section of its byte - the items whose chunk ends its run
+                digit_count(L.hsec, (int)(symA >> 9), valid && symA != 0u && (symA & 511u) != 255u, lane);
             }
         }
     }
     __syncthreads();
     MPH(2)
-    // sections of the expansion: every item but the sentinel (digit 0) stands for one entry in the section of its byte
-    for (int x = tid; x < NB; x += SAM_THREADS) L.hsec[x] = x >= 1 ? hS[x] : 0;
 
     // ---- the items' suffixes: initial order by the keys, regroup, small groups by direct comparison, doubling rounds
     sa_initial_sort<DB>(L, recB, recA, NM, hY, hY, hX, hC, hS, tid);
@@ -1744,7 +1836,13 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     __syncthreads();
     uint32_t m = sa_regroup<true, DB>(L, cy, rcur, NM, sa, rk, tid, (uint32_t *)recA, NM, pairs);
     MPH(4)
+#ifdef SA_PROFILE_ROUNDS
+    if (blockIdx.x == 0 && tid == 0) printf("meta: N=%u items=%u shared after the keys=%u\n", N, NM, m);
+#endif
     m -= sa_finish<DB>(L, cy, (const uint32_t *)recA, NM, sa, rk, T, n, 2, tid, pairs, mpos);
+#ifdef SA_PROFILE_ROUNDS
+    if (blockIdx.x == 0 && tid == 0) printf("meta: shared after the finisher=%u\n", m);
+#endif
     MPH(5)
     isa_flush<DB>(L, pairs, NM, rk, tid);
     MPH(6)
@@ -1752,11 +1850,13 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     __syncthreads();
     MPH(7)
 
-    // ---- expansion, pass P: in rank order, item u is the tail of the chunk before it (and, a deep byte, of itself): the
-    //      entries tail position | chunk length << 20 | type << 28 (0: the tail's byte is smaller than the chunk's, or the
-    //      text ends; 1: larger; 2: deep byte), scattered by the chunk's byte + 1; the bytes of every section are summed
-    const uint32_t m1 = NM - 1;            // entries: one per item but the sentinel (item m1)
+    // ---- expansion, pass P: in rank order, an item u that starts a run (or is the sentinel) is the tail of the run before
+    //      it: the entries  tail position | min(run length, 253) << 20 | type << 28 (0: the tail's byte is smaller than the
+    //      run's, or the text ends; 1: larger) | long << 30 (a run of more than 253 bytes: its length goes to
+    //      runlen[tail]), scattered by the run's byte + 1; the bytes of every section are summed
+    const uint32_t m1 = NM - 1;            // the sentinel's item
     uint32_t *ent = (uint32_t *)recA;
+    uint32_t *runlen = pairs;              // (idle since the items' ranks were flushed)
     int32_t *secbytes = L.tpos;
     for (int x = tid; x < NB; x += SAM_THREADS) secbytes[x] = 0;
     if (tid == 0) cy.next_sec = 1;
@@ -1770,19 +1870,21 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
     }
     for (uint32_t t0 = 0; t0 < NM; t0 += SA_TILE) {
         const uint32_t wb = t0 + (uint32_t)w * SA_WSPAN;
-        uint32_t ea[SA_K], eb[SA_K];
-        int da[SA_K], db[SA_K], la[SA_K], lb[SA_K];
-        bool va[SA_K], vb[SA_K];
-        uint32_t u[SA_K], w0[SA_K], w1[SA_K];
+        uint32_t eb[SA_K];
+        int db[SA_K], lb[SA_K];
+        bool vb[SA_K];
+        uint32_t u[SA_K], w0[SA_K], w1[SA_K], w2[SA_K];
 #pragma unroll
-        for (int s_ = 0; s_ < SA_K; ++s_) {  // the position words of the item and of the item before it (all in flight)
+        for (int s_ = 0; s_ < SA_K; ++s_) {  // the position words of the item and of the two items before it (all in flight)
             const uint32_t r = wb + s_ * 64 + lane;
             u[s_] = un[s_];
             w0[s_] = 0;
             w1[s_] = 0;
+            w2[s_] = 0;
             if (r < NM && MCHK(u[s_] < NM, 20, u[s_], r)) {
                 w1[s_] = mpos[u[s_]];
                 if (u[s_] >= 1) w0[s_] = mpos[u[s_] - 1];
+                if (u[s_] >= 2) w2[s_] = mpos[u[s_] - 2];
             }
         }
         if (t0 + SA_TILE < NM) {  // the next tile's ranks, loaded while this tile is placed
@@ -1798,19 +1900,24 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             const bool ok = r < NM;
             const uint32_t pos_u = w1[s_] & MP_POS_MASK, c_u = (w1[s_] >> MP_BYTE_SHIFT) & 0xFFu, c_p = (w0[s_] >> MP_BYTE_SHIFT) & 0xFFu;
             const bool sentinel = u[s_] == m1;
-            va[s_] = ok && !sentinel && ((w1[s_] >> MP_DEEP_SHIFT) & 1u);
-            da[s_] = (int)c_u + 1;
-            ea[s_] = (pos_u + 1u) | (1u << 20) | (2u << 28);
+            // the item before u ends its run (a chunk of 253 bytes that is followed by the same byte does not)
             vb[s_] = ok && u[s_] >= 1 && !((w0[s_] >> MP_DEEP_SHIFT) & 1u);
-            const uint32_t ell = pos_u - (w0[s_] & MP_POS_MASK);
+            uint32_t ell = pos_u - (w0[s_] & MP_POS_MASK);   // the run's last chunk
+            uint32_t lng = 0;
+            if (vb[s_] && u[s_] >= 2 && ((w2[s_] >> MP_DEEP_SHIFT) & 1u)) {  // ... behind full chunks: a long run (rare)
+                uint32_t len = ell + (uint32_t)(SA_RUN_CAP - 1);
+                for (uint32_t v = u[s_] - 2; v >= 1 && ((mpos[v - 1] >> MP_DEEP_SHIFT) & 1u); --v) len += (uint32_t)(SA_RUN_CAP - 1);
+                runlen[pos_u] = len;
+                lng = 1u << 30;
+                atomicAdd(&secbytes[(int)c_p + 1], (int)len);
+                ell = (uint32_t)(SA_RUN_CAP - 1);
+            } else if (vb[s_]) {
+                atomicAdd(&secbytes[(int)c_p + 1], (int)ell);
+            }
             db[s_] = (int)c_p + 1;
-            eb[s_] = pos_u | (ell << 20) | ((sentinel || c_u < c_p) ? 0u : 1u << 28);
+            eb[s_] = pos_u | (ell << 20) | ((sentinel || c_u < c_p) ? 0u : 1u << 28) | lng;
             lb[s_] = 0;
-            la[s_] = 0;
             if (__ballot(vb[s_])) lb[s_] = tile_rank<9, DB>(L, w, db[s_], vb[s_], lane);
-            if (__ballot(va[s_])) la[s_] = tile_rank<9, DB>(L, w, da[s_], va[s_], lane);
-            if (vb[s_]) atomicAdd(&secbytes[db[s_]], (int)ell);
-            if (va[s_]) atomicAdd(&secbytes[da[s_]], 1);
         }
         tile_prepare<DB>(L, tid);
 #pragma unroll
@@ -1818,10 +1925,6 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             if (vb[s_]) {
                 const int at = L.delta[db[s_]] + (int)L.woff[SaLds<DB>::cell(db[s_], w)] + lb[s_];
                 if (MCHK(at >= 0 && (uint32_t)at < m1, 21, at, eb[s_])) ent[at] = eb[s_];
-            }
-            if (va[s_]) {
-                const int at = L.delta[da[s_]] + (int)L.woff[SaLds<DB>::cell(da[s_], w)] + la[s_];
-                if (MCHK(at >= 0 && (uint32_t)at < m1, 22, at, ea[s_])) ent[at] = ea[s_];
             }
         }
     }
@@ -1865,11 +1968,12 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             tot[tid] = r;
         }
         __syncthreads();
-        if (w == 0) xp_offsets(tot, tot, 1 + L.delta[d], lane, 3);
+        if (w == 0) xp_offsets(tot, tot, 1 + L.delta[d], secbytes[d], lane, 3);
         __syncthreads();
         for (int x = lane; x < XP_TAB; x += 64) run[x] = tot[x] + mine[x];
         __builtin_amdgcn_wave_barrier();
         xp_expand(ent, a, b, run, buf, sa, rk, lane, N);
+        if (w == 0 && tot[254] > 0) xp_long(ent, a0, a0 + cnt, runlen, recB + a0, tot[255], tot[254], sa, rk, lane, N);
         __syncthreads();
     }
     MPH(10)
@@ -1887,8 +1991,10 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         __builtin_amdgcn_wave_barrier();
         const int qmax = xp_count(ent, a, b, run, lane) >> 6;
         xp_levels(run, lane, qmax);
-        xp_offsets(run, run, 1 + L.delta[d], lane, qmax);
+        xp_offsets(run, run, 1 + L.delta[d], secbytes[d], lane, qmax);
+        const int lfirst = run[255], nlong = run[254];
         xp_expand(ent, a, b, run, buf, sa, rk, lane, N);
+        if (nlong > 0) xp_long(ent, a, b, runlen, recB + a, lfirst, nlong, sa, rk, lane, N);
     }
     MPH(11)
     // (no inverse array: the items' ranks have used its buffer, and nothing behind the suffix sort reads more of it than

@@ -13,6 +13,9 @@ print("creating ctx", flush=True)
 ctx = B.new_ctx(b"")
 print("ctx ok", flush=True)
 cases = [b"a", b"ab", b"aa", b"abab", b"\x00" * 10, b"\x00" * 300, b"ab" * 50 + b"\x00" * 260 + b"\x01", synth.blob(0)[:3000], synth.blob(1)[:40000]]
+cases += [b"\x00" * 253 + b"\x01", b"\x00" * 506, b"\x00" * 507 + b"a", b"\x07" * 759 + b"\x01" + b"\x07" * 760 + b"\x09" + b"\x07" * 300,
+          (b"\x00" * 254 + b"\x01") * 80, (b"\x05" * 300 + b"\x01" + b"\x05" * 280 + b"\x09") * 40, b"\x00" * 20000,
+          b"ab" * 3000, b"\xff" * 1000 + b"\x00" * 1000 + b"\xff" * 1001 + b"\x00" * 999]
 import random
 random.seed(5)
 for t in range(6):
