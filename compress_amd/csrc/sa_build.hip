@@ -146,7 +146,7 @@ constexpr int SA_RUN_CAP = 254;  // runs of equal symbols are told apart by leng
 // run-compressed sort (sa_meta_kernel): item i of a text starts at byte mpos[i] & MP_POS_MASK; bits 20-27 hold that
 // byte, bit 28 says that the item is one byte of a run with at least SA_RUN_CAP bytes to go ("deep")
 constexpr uint32_t MP_POS_MASK = (1u << 20) - 1u;
-constexpr int MP_BYTE_SHIFT = 20, MP_DEEP_SHIFT = 28;
+constexpr int MP_BYTE_SHIFT = 20, MP_DEEP_SHIFT = 28, MP_CONT_SHIFT = 29;  // (bit 29: the item is not the first byte of its run)
 
 // Length of the run of equal bytes that starts at position e of the text (1 at and past its end), exact up to 257:
 // the lanes of a wave hold 64 consecutive positions and read the run off five ballots of "byte == next byte".
@@ -1692,7 +1692,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             for (int i = 0; i < 2 * G; ++i) E[i] = flags_of(bb + i, rw[i]);
             for (uint32_t c = bb; c < be; c += G) {
                 int rl_[G];
-                bool it_[G];
+                bool it_[G], hd_[G];
                 uint32_t xv[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -1717,6 +1717,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     eqcar = (E0 >> 63) != 0;
                     // an item: the first byte of a run and every 253rd byte behind it
                     it_[g] = c + g < be && e < N && d % (uint32_t)(SA_RUN_CAP - 1) == 0u;
+                    hd_[g] = d == 0u;
                     xv[g] = 0;
                     if (it_[g] && rl_[g] < SA_RUN_CAP) xv[g] = T[e + (uint32_t)rl_[g]];  // (the text is zero padded)
                 }
@@ -1747,7 +1748,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                         sym = (dS << 9) | dC;
                     }
                     const uint64_t bm = __ballot(it_[g]);
-                    if (it_[g]) stage[cntw + (uint32_t)__popcll(bm & lanemask_lt(lane))] = ((uint64_t)sym << 32) | (uint64_t)e;
+                    if (it_[g]) stage[cntw + (uint32_t)__popcll(bm & lanemask_lt(lane))] = ((uint64_t)sym << 32) | (uint64_t)e | (hd_[g] ? 0ull : 1ull << 31);
                     cntw += (uint32_t)__popcll(bm);
                 }
 #pragma unroll
@@ -1809,19 +1810,32 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
                     nx = (uint64_t)lo | ((uint64_t)hi << 32);
                 }
                 if (j + 1 == cntw) nx = wnext;
-                const uint32_t symA = (uint32_t)(it >> 32), e = (uint32_t)it, symB = (uint32_t)(nx >> 32);
+                const uint32_t symA = (uint32_t)(it >> 32), e = (uint32_t)it & MP_POS_MASK, symB = (uint32_t)(nx >> 32);
+                const uint32_t cont = ((uint32_t)it >> 31) & 1u;  // the item continues a run (behind a full chunk)
                 const uint32_t i = base_w + j;
                 if (valid) {
-                    mpos[i] = e | ((((symA >> 9) - 1u) & 0xFFu) << MP_BYTE_SHIFT) | ((symA & 511u) == 255u ? 1u << MP_DEEP_SHIFT : 0u);
+                    mpos[i] = e | ((((symA >> 9) - 1u) & 0xFFu) << MP_BYTE_SHIFT) | ((symA & 511u) == 255u ? 1u << MP_DEEP_SHIFT : 0u) | (cont << MP_CONT_SHIFT);
                     recB[i] = ((((uint64_t)symA << 18) | (uint64_t)symB) << 20) | (uint64_t)i;
                 }
-                digit_count(hY, (int)(symB & 511u), valid, lane);
-                digit_count(hX, (int)(symB >> 9), valid, lane);
+                // the digits of the item's own symbol are counted; the next item's (the low half of the key) follow from
+                // them below.  (Five leader-vote counts per step were 8 % of the kernel: LDS atomics of many lanes on one word.)
                 digit_count(hC, (int)(symA & 511u), valid, lane);
                 digit_count(hS, (int)(symA >> 9), valid, lane);
-                // sections of the expansion: one entry per run, in the section of its byte - the items whose chunk ends its run
-                digit_count(L.hsec, (int)(symA >> 9), valid && symA != 0u && (symA & 511u) != 255u, lane);
+                // full chunks (253 bytes of a run that goes on): they end no run, so they stand for no entry of the expansion
+                const bool full = valid && (symA & 511u) == 255u;
+                if (__ballot(full)) digit_count(L.hsec, (int)(symA >> 9), full, lane);
             }
+        }
+    }
+    __syncthreads();
+    {   // the low half of item i's key is the symbol of item i + 1 (nothing for the last item, the sentinel): its digits
+        // are the symbols' digits without the first item's and with one more zero.  Sections of the expansion: one entry
+        // per run in the section of its byte + 1 - every item but the sentinel (digit 0) and the full chunks.
+        const uint32_t sym0 = (uint32_t)(recA[0] >> 32);  // (position 0 is an item, the first of wave 0's)
+        for (int x = tid; x < NB; x += SAM_THREADS) {
+            hX[x] = hS[x] + (x == 0 ? 1 : 0) - (x == (int)(sym0 >> 9) ? 1 : 0);
+            hY[x] = hC[x] + (x == 0 ? 1 : 0) - (x == (int)(sym0 & 511u) ? 1 : 0);
+            L.hsec[x] = x >= 1 ? hS[x] - L.hsec[x] : 0;
         }
     }
     __syncthreads();
@@ -1873,18 +1887,16 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
         uint32_t eb[SA_K];
         int db[SA_K], lb[SA_K];
         bool vb[SA_K];
-        uint32_t u[SA_K], w0[SA_K], w1[SA_K], w2[SA_K];
+        uint32_t u[SA_K], w0[SA_K], w1[SA_K];
 #pragma unroll
-        for (int s_ = 0; s_ < SA_K; ++s_) {  // the position words of the item and of the two items before it (all in flight)
+        for (int s_ = 0; s_ < SA_K; ++s_) {  // the position words of the item and of the item before it (all in flight)
             const uint32_t r = wb + s_ * 64 + lane;
             u[s_] = un[s_];
             w0[s_] = 0;
             w1[s_] = 0;
-            w2[s_] = 0;
             if (r < NM && MCHK(u[s_] < NM, 20, u[s_], r)) {
                 w1[s_] = mpos[u[s_]];
                 if (u[s_] >= 1) w0[s_] = mpos[u[s_] - 1];
-                if (u[s_] >= 2) w2[s_] = mpos[u[s_] - 2];
             }
         }
         if (t0 + SA_TILE < NM) {  // the next tile's ranks, loaded while this tile is placed
@@ -1904,7 +1916,7 @@ __global__ __launch_bounds__(SAM_THREADS) __attribute__((amdgpu_waves_per_eu(SAM
             vb[s_] = ok && u[s_] >= 1 && !((w0[s_] >> MP_DEEP_SHIFT) & 1u);
             uint32_t ell = pos_u - (w0[s_] & MP_POS_MASK);   // the run's last chunk
             uint32_t lng = 0;
-            if (vb[s_] && u[s_] >= 2 && ((w2[s_] >> MP_DEEP_SHIFT) & 1u)) {  // ... behind full chunks: a long run (rare)
+            if (vb[s_] && ((w0[s_] >> MP_CONT_SHIFT) & 1u)) {  // ... behind full chunks: a long run (rare)
                 uint32_t len = ell + (uint32_t)(SA_RUN_CAP - 1);
                 for (uint32_t v = u[s_] - 2; v >= 1 && ((mpos[v - 1] >> MP_DEEP_SHIFT) & 1u); --v) len += (uint32_t)(SA_RUN_CAP - 1);
                 runlen[pos_u] = len;
