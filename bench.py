@@ -72,6 +72,8 @@ def pmc_traffic(stage, n_blobs):
         k = k.replace("void ", "").split("<")[0]
         if k == "lzss::lcp_lds_kernel":
             k = "lzss::lcp_kernel"
+        if k == "lzss::sa_meta_kernel":      # the run-compressed suffix sort (round 3) is the sa_build stage's kernel
+            k = "lzss::sa_build_kernel"
         if k == kernel and c == "FETCH_SIZE":
             fetch += float(v) * 1024.0
         if k == kernel and c == "WRITE_SIZE":
