@@ -61,6 +61,43 @@ def test_index_matches_oracle(amd):
             assert lcp[r] == l
 
 
+def run_cases():
+    """inputs for the run-compressed suffix sort (sa_meta_kernel): runs whose lengths sit around the chunk length of 253
+    and its multiples, long runs followed by smaller / larger bytes / the end of the text, more than 64 long runs of one
+    byte (xp_long's list), sections with more than 1024 runs (expanded by all waves) and with many levels"""
+    rng = np.random.default_rng(253)
+    cases = [bytes(n) for n in (252, 253, 254, 255, 505, 506, 507, 508, 759, 760, 1012, 1013, 20000)]
+    cases += [bytes(253) + b"\x01", bytes(254) + b"\x01" + bytes(506), b"\x09" * 300 + b"\x01" + b"\x09" * 301 + b"\xf0" + b"\x09" * 253,
+              (bytes(254) + b"\x01") * 80, (b"\x05" * 300 + b"\x01" + b"\x05" * 280 + b"\x09") * 40,
+              b"\xff" * 1000 + bytes(1000) + b"\xff" * 1001 + bytes(999), b"ab" * 3000, b"a" * 253 + b"b" * 253 + b"a" * 254 + b"b" * 252]
+    t = bytearray()
+    while len(t) < 60000:        # thousands of short runs of few bytes: big sections, many levels
+        t += bytes([int(rng.integers(0, 3))]) * int(rng.integers(1, 40))
+    cases.append(bytes(t))
+    t = bytearray()
+    while len(t) < 90000:        # long runs of every length between random bytes
+        t += bytes([int(rng.integers(0, 2)) * 255]) * int(rng.integers(200, 330)) + bytes(rng.integers(0, 256, int(rng.integers(1, 4)), dtype=np.uint8))
+    cases.append(bytes(t))
+    return cases
+
+
+def test_run_compressed_sort_matches_oracle(amd):
+    cases = run_cases()
+    ctx = amd.batch.new_ctx(b"")
+    b = amd.batch.Batch(ctx, len(cases), sum(map(len, cases)))
+    b.upload(cases)
+    b.compress()
+    outs = b.download()
+    oc = O.Compressor(b"")
+    for k, d in enumerate(cases):
+        sa, isa, lcp = b.index(k)
+        ref = O.suffix_array(d)
+        assert sa[0] == len(d)
+        assert np.array_equal(sa[1:], ref), f"case {k} n={len(d)}"
+        assert np.array_equal(isa[sa], np.arange(len(d) + 1))
+        assert outs[k] == oc.compress(d), f"case {k}"
+
+
 def small_group_cases():
     """inputs that stress the suffix sort's small-group finisher (sa_finish) and the LDS / global LCP kernels"""
     rng = np.random.default_rng(11)
