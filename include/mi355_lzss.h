@@ -90,7 +90,7 @@ int mi355_lzss_write(mi355_lzss_ctx *ctx, const uint8_t *inbuf, size_t n, size_t
  * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  It calls no hipMalloc /
  * hipFree / allocating routine and does not synchronise: the kernels of mi355_lzss_write are enqueued on
  * `stream` (a hipStream_t; NULL = the default stream) with their ~37 bytes per position of workspace in a
- * static device array of the library (5.3 MB held by every GPU the library runs on until the process
+ * static device array of the library (5.8 MB held by every GPU the library runs on until the process
  * ends).  d_inbuf, d_out, d_nbits, d_status are DEVICE pointers: inbuf[0:n) in, the packed bits in
  * d_out (zero padded, layout as above), *d_nbits = phrase bits, *d_status = 0 or MI355_LZSS_E_CAPACITY
  * (then d_out holds nothing useful); all valid once the stream has reached the end of the call's work.
