@@ -23,7 +23,7 @@ constexpr int32_t ST_FORMAT = -6;    // MI355_LZSS_E_FORMAT
 constexpr int32_t ST_CAPACITY = -5;  // MI355_LZSS_E_CAPACITY
 
 constexpr int DEC_WIN = 2048;        // bytes of the stream staged in LDS
-constexpr int DEC_NEED = 64 + 8;     // bytes one step may look at from its first byte on
+constexpr int DEC_NEED = 64 + 16;    // bytes one step may look at from its first byte on (the fast loop reads three words per lane)
 
 typedef uint32_t dec_u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -77,7 +77,99 @@ __global__ __launch_bounds__(64) void decompress_kernel(const uint8_t *in, const
     uint32_t wbase = 0;
     int32_t st = 0;
 
-    for (;;) {
+    // ---- fast loop: while a whole step (64 symbols and a reference behind any of the first 60) lies inside the stream
+    //      and its output (64 literals and 256 copied bytes) inside the capacity, nothing has to be checked against the
+    //      ends.  With a whole batch resident the scalar unit, which the waves of a CU share, bounds this kernel, so the
+    //      step is written for few scalar instructions: every lane takes the 40 bits at its bit position from three
+    //      words of the window (funnel shifts) and decodes them as if a reference started there (vector work, the same
+    //      for all lanes); after the ballot for the first reserved symbol ONE v_readlane brings the fields of the
+    //      reference, and the copy addresses are 32-bit lane offsets from a scalar base.
+    const uint32_t *s_w = reinterpret_cast<const uint32_t *>(s_in);
+    const uint32_t k4 = 4u * (uint32_t)lane;
+    // (scalar compares feeding branches directly, rare cases out of line: the step's control flow is what the scalar
+    // unit spends its time on)
+    const uint32_t b_lim = total >= 512u ? total - 512u : 0u;   // the fast loop runs while b <= b_lim (and total >= 512)
+    const uint32_t o_lim = cap32 >= 320u ? cap32 - 320u : 0u;   // ... and opos <= o_lim (and cap32 >= 320)
+    uint32_t b_stop = 0;  // min(b_lim, last bit position the window serves); 0: no window yet
+    if (total >= 512u && cap32 >= 320u) {
+        for (;;) {
+            if (__builtin_expect(b > b_stop, 0)) {
+                if (b > b_lim) break;
+                wbase = (b >> 3) & ~15u;
+                wend = wbase + DEC_WIN;
+                for (int j = lane; j < DEC_WIN / 16; j += 64) {
+                    const uint32_t o = wbase + 16u * (uint32_t)j;
+                    dec_u32x4_t v = {0u, 0u, 0u, 0u};
+                    if (o <= (uint32_t)n) {
+                        typedef dec_u32x4_t unaligned_t __attribute__((aligned(1)));
+                        v = *reinterpret_cast<const unaligned_t *>(src + o);
+                    }
+                    *reinterpret_cast<dec_u32x4_t *>(s_in + 16 * j) = v;
+                }
+                __syncthreads();
+                const uint32_t wlast = (wend - DEC_NEED) * 8u + 7u;  // last bit position whose step the window serves
+                b_stop = wlast < b_lim ? wlast : b_lim;
+            }
+            if (__builtin_expect(opos > o_lim, 0)) break;
+            const uint32_t bi = (b >> 3) - wbase + (uint32_t)lane;
+            const uint32_t di = bi >> 2, rr = bi & 3u;
+            const uint32_t w0 = s_w[di], w1 = s_w[di + 1], w2 = s_w[di + 2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, rr), hi = __builtin_amdgcn_alignbyte(w2, w1, rr);
+            const uint64_t be = (((uint64_t)__builtin_bswap32(lo) << 32) | (uint64_t)__builtin_bswap32(hi)) << (b & 7u);
+            const uint32_t T = (uint32_t)(be >> 32), U = (uint32_t)be;  // the 64 bits from bit b + 8 lane on, MSB first
+            const uint32_t sv = T >> 24;
+            const uint64_t mask = __ballot(sv >= LZSS_SYMBOL_SHORT);
+            const uint32_t f = mask ? (uint32_t)__builtin_ctzll(mask) : 64u;  // number of literals in front of the reference
+            if ((uint32_t)lane < f) dst[opos + (uint32_t)lane] = (uint8_t)sv;
+            opos += f;
+            b += 8u * f;
+            if (f > 59u) continue;  // all literals, or the reference's 37 bits are not all inside the lanes' words
+            // backref.go:70-86 for the reference that would start at this lane: delimiter(8) | length-1 (8) | offset-1 (14 | 21)
+            const uint32_t offl = __builtin_amdgcn_alignbit(T, U, 27) & 0x1FFFFFu, offs = (T >> 2) & 0x3FFFu;
+            const uint32_t pk = (sv == LZSS_SYMBOL_SHORT ? (offs | (1u << 29)) : offl) | (((T >> 16) & 0xFFu) << 21);
+            const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)f);
+            const uint32_t len = ((P >> 21) & 0xFFu) + 1, off = (P & 0x1FFFFFu) + 1;
+            const uint32_t nb = LZSS_DYN_BITS - (LZSS_DYN_BITS - LZSS_SHORT_BITS) * (P >> 29);
+            if (__builtin_expect(off > opos, 0)) {
+                // the reference starts in the dictionary and must end there (decompress.go:65-70); a short one cannot (:53-55)
+                const uint32_t back = off - opos;
+                if ((P >> 29) != 0 || back > dict_len || len > back) { st = ST_FORMAT; break; }
+                const uint32_t so = dict_len - back;
+                for (uint32_t k = lane; k < len; k += 64) dst[opos + k] = dict[so + k];
+            } else {
+                const uint32_t so = opos - off;  // where the source starts in the output
+                if (__builtin_expect(off < len, 0)) {
+                    // offset < length (the run-length encodings of compress.go:175-218): source byte k mod offset
+                    if (so + off > fenced) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    for (uint32_t k = lane; k < len; k += 64) dst[opos + k] = dst[so + k % off];
+                } else {
+                    // the wait in front of every copy's store also ends all stores before it, so the only bytes that may
+                    // still be on their way are the previous copy's and the literals since: [fenced, opos)
+                    if (__builtin_expect(so + len > fenced, 0)) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    if (__builtin_expect(len < 4u, 0)) {
+                        if ((uint32_t)lane < len) dst[opos + (uint32_t)lane] = dst[so + (uint32_t)lane];
+                    } else if (k4 < len) {  // four bytes per lane; the last lane's word ends with the copy (it overlaps its neighbour's)
+                        const uint32_t o = k4 + 4 <= len ? k4 : len - 4;
+                        st4u(dst + (opos + o), ld4u(dst + (so + o)));
+                    }
+                }
+            }
+            fenced = opos;
+            opos += len;
+            b += nb;
+        }
+    }
+
+    // ---- the ends of the stream and of the capacity: the same step with every check
+    if (st == 0) for (;;) {
         // ---- the window must hold the bytes this step may look at
         const uint32_t byte0 = b >> 3;
         if (byte0 + DEC_NEED > wend) {
@@ -127,7 +219,6 @@ __global__ __launch_bounds__(64) void decompress_kernel(const uint8_t *in, const
         if (b + nb > total) { st = ST_FORMAT; break; }  // truncated reference: readFrom returns the EOF
         if (opos + len > cap32) { st = ST_CAPACITY; break; }
         uint8_t *d0 = dst + opos;
-        const uint32_t k4 = 4u * (uint32_t)lane;
         if (off > opos) {
             // the reference starts in the dictionary and must end there (decompress.go:65-70); a short one cannot (:53-55)
             const uint32_t back = off - opos;  // bytes before the end of the dictionary
