@@ -90,81 +90,90 @@ __global__ __launch_bounds__(64) void decompress_kernel(const uint8_t *in, const
     // unit spends its time on)
     const uint32_t b_lim = total >= 512u ? total - 512u : 0u;   // the fast loop runs while b <= b_lim (and total >= 512)
     const uint32_t o_lim = cap32 >= 320u ? cap32 - 320u : 0u;   // ... and opos <= o_lim (and cap32 >= 320)
-    uint32_t b_stop = 0;  // min(b_lim, last bit position the window serves); 0: no window yet
     if (total >= 512u && cap32 >= 320u) {
         for (;;) {
-            if (__builtin_expect(b > b_stop, 0)) {
-                if (b > b_lim) break;
-                wbase = (b >> 3) & ~15u;
-                wend = wbase + DEC_WIN;
-                for (int j = lane; j < DEC_WIN / 16; j += 64) {
-                    const uint32_t o = wbase + 16u * (uint32_t)j;
-                    dec_u32x4_t v = {0u, 0u, 0u, 0u};
-                    if (o <= (uint32_t)n) {
-                        typedef dec_u32x4_t unaligned_t __attribute__((aligned(1)));
-                        v = *reinterpret_cast<const unaligned_t *>(src + o);
-                    }
-                    *reinterpret_cast<dec_u32x4_t *>(s_in + 16 * j) = v;
+            // the window serves the steps that start at bits [.., b_stop]
+            if (b > b_lim || opos > o_lim || st != 0) break;
+            wbase = (b >> 3) & ~15u;
+            wend = wbase + DEC_WIN;
+            for (int j = lane; j < DEC_WIN / 16; j += 64) {
+                const uint32_t o = wbase + 16u * (uint32_t)j;
+                dec_u32x4_t v = {0u, 0u, 0u, 0u};
+                if (o <= (uint32_t)n) {
+                    typedef dec_u32x4_t unaligned_t __attribute__((aligned(1)));
+                    v = *reinterpret_cast<const unaligned_t *>(src + o);
                 }
-                __syncthreads();
-                const uint32_t wlast = (wend - DEC_NEED) * 8u + 7u;  // last bit position whose step the window serves
-                b_stop = wlast < b_lim ? wlast : b_lim;
+                *reinterpret_cast<dec_u32x4_t *>(s_in + 16 * j) = v;
             }
-            if (__builtin_expect(opos > o_lim, 0)) break;
-            const uint32_t bi = (b >> 3) - wbase + (uint32_t)lane;
-            const uint32_t di = bi >> 2, rr = bi & 3u;
-            const uint32_t w0 = s_w[di], w1 = s_w[di + 1], w2 = s_w[di + 2];
-            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, rr), hi = __builtin_amdgcn_alignbyte(w2, w1, rr);
-            const uint64_t be = (((uint64_t)__builtin_bswap32(lo) << 32) | (uint64_t)__builtin_bswap32(hi)) << (b & 7u);
-            const uint32_t T = (uint32_t)(be >> 32), U = (uint32_t)be;  // the 64 bits from bit b + 8 lane on, MSB first
-            const uint32_t sv = T >> 24;
-            const uint64_t mask = __ballot(sv >= LZSS_SYMBOL_SHORT);
-            const uint32_t f = mask ? (uint32_t)__builtin_ctzll(mask) : 64u;  // number of literals in front of the reference
-            if ((uint32_t)lane < f) dst[opos + (uint32_t)lane] = (uint8_t)sv;
-            opos += f;
-            b += 8u * f;
-            if (f > 59u) continue;  // all literals, or the reference's 37 bits are not all inside the lanes' words
-            // backref.go:70-86 for the reference that would start at this lane: delimiter(8) | length-1 (8) | offset-1 (14 | 21)
-            const uint32_t offl = __builtin_amdgcn_alignbit(T, U, 27) & 0x1FFFFFu, offs = (T >> 2) & 0x3FFFu;
-            const uint32_t pk = (sv == LZSS_SYMBOL_SHORT ? (offs | (1u << 29)) : offl) | (((T >> 16) & 0xFFu) << 21);
-            const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)f);
-            const uint32_t len = ((P >> 21) & 0xFFu) + 1, off = (P & 0x1FFFFFu) + 1;
-            const uint32_t nb = LZSS_DYN_BITS - (LZSS_DYN_BITS - LZSS_SHORT_BITS) * (P >> 29);
-            if (__builtin_expect(off > opos, 0)) {
-                // the reference starts in the dictionary and must end there (decompress.go:65-70); a short one cannot (:53-55)
-                const uint32_t back = off - opos;
-                if ((P >> 29) != 0 || back > dict_len || len > back) { st = ST_FORMAT; break; }
-                const uint32_t so = dict_len - back;
-                for (uint32_t k = lane; k < len; k += 64) dst[opos + k] = dict[so + k];
-            } else {
-                const uint32_t so = opos - off;  // where the source starts in the output
-                if (__builtin_expect(off < len, 0)) {
-                    // offset < length (the run-length encodings of compress.go:175-218): source byte k mod offset
-                    if (so + off > fenced) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    for (uint32_t k = lane; k < len; k += 64) dst[opos + k] = dst[so + k % off];
-                } else {
-                    // the wait in front of every copy's store also ends all stores before it, so the only bytes that may
-                    // still be on their way are the previous copy's and the literals since: [fenced, opos)
-                    if (__builtin_expect(so + len > fenced, 0)) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    if (__builtin_expect(len < 4u, 0)) {
+            __syncthreads();
+            const uint32_t wlast = (wend - DEC_NEED) * 8u + 7u;  // last bit position whose step the window serves
+            uint32_t b_stop = wlast < b_lim ? wlast : b_lim;
+            // one exit, at the top: a step that must leave (capacity, malformed reference) clears b_stop
+            while (b <= b_stop) {
+                if (__builtin_expect(opos > o_lim, 0)) { b_stop = 0; continue; }
+                const uint32_t bi = (b >> 3) - wbase + (uint32_t)lane;
+                const uint32_t di = bi >> 2, rr = bi & 3u;
+                const uint32_t w0 = s_w[di], w1 = s_w[di + 1], w2 = s_w[di + 2];
+                const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, rr), hi = __builtin_amdgcn_alignbyte(w2, w1, rr);
+                const uint64_t be = (((uint64_t)__builtin_bswap32(lo) << 32) | (uint64_t)__builtin_bswap32(hi)) << (b & 7u);
+                const uint32_t T = (uint32_t)(be >> 32), U = (uint32_t)be;  // the 64 bits from bit b + 8 lane on, MSB first
+                const uint32_t sv = T >> 24;
+                // literals in front of the first reserved symbol (lane 63 counts as one: a step takes 63 literals at most)
+                uint32_t f;  // (as asm: the compiler carries the count of trailing zeros as a 64-bit value into every compare)
+                asm("s_ff1_i32_b64 %0, %1" : "=s"(f) : "s"(__ballot(sv >= LZSS_SYMBOL_SHORT) | (1ull << 63)));
+                if ((uint32_t)lane < f) dst[opos + (uint32_t)lane] = (uint8_t)sv;
+                opos += f;
+                b += 8u * f;
+                if (f > 59u) continue;  // all literals, or the reference's 37 bits are not all inside the lanes' words
+                // backref.go:70-86 for the reference that would start at this lane: delimiter(8) | length-1 (8) | offset-1
+                // (14 | 21); and whether it is one of the plain ones: source inside the output, in memory, not
+                // overlapping its destination.  opos - off wraps for a source in the dictionary, which fails the first test
+                const uint32_t lng = sv & 1u;  // 0xFF: the long form (selects are written as bit operations: no lane branches)
+                const uint32_t lmask = 0u - lng;
+                const uint32_t offm1 = (__builtin_amdgcn_alignbit(T, U, 27) & 0x1FFFFFu & lmask) | ((T >> 2) & 0x3FFFu & ~lmask);
+                const uint32_t lenm1 = (T >> 16) & 0xFFu;
+                const uint32_t sol = opos - offm1 - 1u;
+                const uint32_t special = (uint32_t)(sol + lenm1 >= fenced) | (uint32_t)(offm1 < lenm1);
+                const uint32_t pk = offm1 | (lenm1 << 21) | (lng << 29) | (special << 30);
+                const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)f);
+                const uint32_t len = ((P >> 21) & 0xFFu) + 1;
+                const uint32_t nb = (P & (1u << 29)) ? LZSS_DYN_BITS : LZSS_SHORT_BITS;
+                if (__builtin_expect((P & (1u << 30)) == 0, 1)) {
+                    const uint32_t so = opos + ~(P & 0x1FFFFFu);  // opos - off
+                    if (len <= 64u) {
                         if ((uint32_t)lane < len) dst[opos + (uint32_t)lane] = dst[so + (uint32_t)lane];
                     } else if (k4 < len) {  // four bytes per lane; the last lane's word ends with the copy (it overlaps its neighbour's)
                         const uint32_t o = k4 + 4 <= len ? k4 : len - 4;
                         st4u(dst + (opos + o), ld4u(dst + (so + o)));
                     }
+                } else {
+                    const uint32_t off = (P & 0x1FFFFFu) + 1;
+                    if (off > opos) {
+                        // the reference starts in the dictionary and must end there (decompress.go:65-70); a short one cannot (:53-55)
+                        const uint32_t back = off - opos;
+                        if (!(P & (1u << 29)) || back > dict_len || len > back) { st = ST_FORMAT; b_stop = 0; continue; }
+                        const uint32_t so = dict_len - back;
+                        for (uint32_t k = lane; k < len; k += 64) dst[opos + k] = dict[so + k];
+                    } else {
+                        // the source reaches bytes that may still be on their way - the wait in front of every copy's store
+                        // also ends all stores before it, so those are the previous copy's and the literals since,
+                        // [fenced, opos) -, or overlaps the destination (offset < length, the run-length encodings of
+                        // compress.go:175-218: source byte k mod offset)
+                        const uint32_t so = opos - off;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (off >= len) {
+                            for (uint32_t k = lane; k < len; k += 64) dst[opos + k] = dst[so + k];
+                        } else {
+                            for (uint32_t k = lane; k < len; k += 64) dst[opos + k] = dst[so + k % off];
+                        }
+                    }
                 }
+                fenced = opos;
+                opos += len;
+                b += nb;
             }
-            fenced = opos;
-            opos += len;
-            b += nb;
         }
     }
 
