@@ -217,6 +217,7 @@ static BatchIndex batch_index(mi355_lzss_batch *b) {
     ix.rlen = b->rlen.as<uint8_t>();
     ix.lcp = b->lcp.as<uint16_t>(); ix.bmin1 = b->b1.as<uint16_t>(); ix.bmin2 = b->b2.as<uint16_t>();
     ix.win = b->sortA.as<uint64_t>();  // a segment's part of the sort buffer is free once the segment is sorted
+    ix.pkey = b->sortB.as<uint64_t>();  // ... and so is its part of the second one
     ix.pmin1 = b->pmin1.as<int32_t>(); ix.pmax1 = b->pmax1.as<int32_t>();
     ix.pmin2 = b->pmin2.as<int32_t>(); ix.pmax2 = b->pmax2.as<int32_t>();
     ix.samin1 = b->samin1.as<int32_t>(); ix.samin2 = b->samin2.as<int32_t>();

@@ -49,6 +49,9 @@ struct BatchIndex {   // batch-wide index arrays
     int32_t *sa, *isa;
     uint16_t *lcp;    // [seg.off + k]
     const uint8_t *rlen;  // [seg.off + i] run of equal bytes starting at position i, capped at 255 (sa_build)
+    // [seg.off + k] what match_kernel needs to know about the pattern at rank k (match.hip: pattern_word), written by the
+    // LCP kernels.  It lives in the suffix sort's SECOND record buffer, which nothing uses once the segment is sorted.
+    uint64_t *pkey;
     uint16_t *bmin1;  // [seg.off/64 + k/64]
     uint16_t *bmin2;  // [seg.off/64 + k/4096]
     // window index (sa_build.hip: window_index_kernel): the ranks 1..n regrouped by the 16 KiB chunk of their

@@ -59,6 +59,85 @@ constexpr int LCP_THREADS = 256;
 #endif
 constexpr int MATCH_THREADS = MATCH_BLOCK;
 
+// ---- dictionary lookup (compress.go:463: LookupLongest over [0, dictLen)) -----------------------
+// Run-aware 8-byte key of the string s[0:A), A >= 1 (readable 8 bytes past A, zeros there): first byte c (8 bits),
+// run code (9 bits), the 5 bytes after the run of c (40 bits, zero padded).  Run code: rl = length of the run of c
+// the string starts with; strings whose run ends in a smaller byte (or ends the string) come first, shorter runs
+// first: code rl (1..253); then runs of >= DICT_RUN_CAP: code 255, no tail; then strings whose run ends in a larger
+// byte, longer runs first: code 511 - rl.  The key order is the string order (a proper prefix is smaller), and two
+// different keys also give the exact common prefix length (key_lcp) - so on zero-heavy data, where a plain 8-byte
+// prefix ties on every probe and every tie costs a text compare, almost every probe is decided by one load.
+constexpr int DICT_RUN_CAP = 254;
+// run: the length of the run of s[0] at s if the caller knows it (the text's `rlen`, capped at 255; it may exceed A), else < 0.
+// w0: the first 8 bytes of s (little-endian load); a run of up to 3 leaves the whole tail inside it, so the common
+// case costs no load of its own
+// (ld_at(o): the 8 bytes at s + o; rl: the length of the run of s[0] at s, capped at 255, it may exceed A)
+template <class LdAt>
+__device__ inline uint64_t run_key_t(int A, int &rlc, int run, uint64_t w0, LdAt ld_at) {
+    const uint32_t c = (uint32_t)(w0 & 0xFFull);
+    const int lim = (A - 1) < DICT_RUN_CAP ? (A - 1) : DICT_RUN_CAP;
+    const int rl = run < lim + 1 ? run : lim + 1;
+    if (rl >= DICT_RUN_CAP) {
+        rlc = DICT_RUN_CAP;
+        return ((uint64_t)c << 49) | (255ull << 40);
+    }
+    rlc = rl;
+    uint64_t tail = 0;
+    bool falling = true;
+    if (rl < A) {
+        const int avail = A - rl;
+        const uint64_t w = rl <= 3 ? (w0 >> (8 * rl)) : ld_at(rl);
+        tail = (__builtin_bswap64(w) >> 24) & ((1ull << 40) - 1ull);
+        if (avail < 5) tail &= ~((1ull << (8 * (5 - avail))) - 1ull);
+        falling = (uint32_t)(w & 0xFFull) < c;
+    }
+    const uint64_t code = falling ? (uint64_t)rl : (uint64_t)(511 - rl);
+    return ((uint64_t)c << 49) | (code << 40) | tail;
+}
+__device__ inline uint64_t run_key_w(const uint8_t *s, int A, int &rlc, int run, uint64_t w0) {
+    if (run < 0) {
+        const int lim = (A - 1) < DICT_RUN_CAP ? (A - 1) : DICT_RUN_CAP;
+        run = 1 + lcp_bytes(s, s + 1, 0, lim);
+    }
+    return run_key_t(A, rlc, run, w0, [&](int o) { return ld8(s + o); });
+}
+// the run length a key vouches for (what run_key_t returns as rlc)
+__device__ inline int key_run(uint64_t k) {
+    const int code = (int)(k >> 40) & 511;
+    return code == 255 ? DICT_RUN_CAP : (code < 255 ? code : 511 - code);
+}
+// What match_kernel needs to know about the pattern at a rank, written by the LCP kernels (which have the suffix's
+// first bytes and its run length at hand, the LDS one at LDS cost) so that match_kernel reads one coalesced word per
+// rank instead of gathering text and run lengths by position: the pattern's run-aware key (57 bits; its first byte
+// tells a reserved symbol), and in bit 63 whether the phrase walk can never ask about the position - it, the two
+// positions before it and at least LZSS_MIN_REPEAT bytes behind it lie in one run (compress.go:184: the RLE branch is
+// taken at i, i - 1 and i - 2; match_kernel used to read that off the run length at i - 2).
+constexpr uint64_t PKEY_SKIP = 1ull << 63, PKEY_KEY_MASK = (1ull << 57) - 1ull;
+template <class LdAt>
+__device__ inline uint64_t pattern_word(uint32_t n, uint32_t pos, uint64_t w0, int run, LdAt ld_at /* 8 bytes at pos + o, o >= -2 */) {
+    if (pos >= n) return 0;  // the sentinel
+    const int A = (int)(n - pos) < LZSS_MAX_LEN ? (int)(n - pos) : LZSS_MAX_LEN;
+    int rlc;
+    uint64_t k = run_key_t(A, rlc, run, w0, ld_at);
+    if (run >= LZSS_MIN_REPEAT && pos >= 2) {
+        const uint64_t b = ld_at(-2);
+        const uint32_t c = (uint32_t)(w0 & 0xFFull);
+        if ((uint32_t)(b & 0xFFull) == c && (uint32_t)((b >> 8) & 0xFFull) == c) k |= PKEY_SKIP;
+    }
+    return k;
+}
+__device__ inline uint64_t run_key(const uint8_t *s, int A, int &rlc) { return run_key_w(s, A, rlc, -1, ld8(s)); }
+// common prefix length of two strings from their (different) keys; the caller caps it by the strings' lengths
+__device__ inline int key_lcp(uint64_t a, uint64_t b) {
+    if ((a ^ b) >> 49) return 0;
+    const int ca = (int)(a >> 40) & 511, cb = (int)(b >> 40) & 511;
+    const int ra = ca == 255 ? DICT_RUN_CAP : (ca < 255 ? ca : 511 - ca);
+    const int rb = cb == 255 ? DICT_RUN_CAP : (cb < 255 ? cb : 511 - cb);
+    if (ca != cb) return ra < rb ? ra : rb;
+    const uint64_t x = (a ^ b) & ((1ull << 40) - 1ull);
+    return ra + (((int)__builtin_clzll(x) - 24) >> 3);
+}
+
 // ---- LCP array and its block minima -------------------------------------------------------------
 __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint32_t n_segs, uint32_t gx, BatchIndex ix) {
     const uint32_t vb = xcd_block(blockIdx.x, gridDim.x);  // a segment's text and run lengths meet in one XCD's L2
@@ -107,6 +186,7 @@ __global__ __launch_bounds__(LCP_THREADS) void lcp_kernel(const Seg *segs, uint3
         ix.lcp[sg.off + k] = (uint16_t)l;
         if (k == N - 1)  // the upward walk of match_kernel reads up to three ranks past N and must die there
             for (uint32_t e = 0; e < 4; ++e) ix.lcp[sg.off + N + e] = 0;
+        ix.pkey[sg.off + k] = pattern_word(sg.n, (uint32_t)sak, wb, rb, [&](int o) { return ld8(T + sak + o); });
     }
     // minimum of LCP and of SA over the 64 ranks of this wave
     const uint32_t m = (uint32_t)wave_min((int)l);  // (l <= 0xFFFF: the signed minimum is the unsigned one)
@@ -223,6 +303,7 @@ __global__ __launch_bounds__(LCPL_THREADS) void lcp_lds_kernel(const Seg *segs, 
             ix.lcp[sg.off + k] = (uint16_t)l;
             if (k == N - 1)
                 for (uint32_t e = 0; e < 4; ++e) ix.lcp[sg.off + N + e] = 0;
+            ix.pkey[sg.off + k] = pattern_word(n, (uint32_t)sak, wb, rb, [&](int o) { return ld8s((uint32_t)(sak + o)); });
         }
         const uint32_t m = (uint32_t)wave_min((int)l);  // (l <= 0xFFFF: the signed minimum is the unsigned one)
         const int ms = wave_min(sak);
@@ -266,51 +347,6 @@ void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchI
     const uint32_t nb1 = (N + 63) / 64;
     dim3 g2((nb1 + 63) / 64, n_segs);
     hipLaunchKernelGGL(bmin2_kernel, g2, dim3(64), 0, stream, d_segs, ix);
-}
-
-// ---- dictionary lookup (compress.go:463: LookupLongest over [0, dictLen)) -----------------------
-// Run-aware 8-byte key of the string s[0:A), A >= 1 (readable 8 bytes past A, zeros there): first byte c (8 bits),
-// run code (9 bits), the 5 bytes after the run of c (40 bits, zero padded).  Run code: rl = length of the run of c
-// the string starts with; strings whose run ends in a smaller byte (or ends the string) come first, shorter runs
-// first: code rl (1..253); then runs of >= DICT_RUN_CAP: code 255, no tail; then strings whose run ends in a larger
-// byte, longer runs first: code 511 - rl.  The key order is the string order (a proper prefix is smaller), and two
-// different keys also give the exact common prefix length (key_lcp) - so on zero-heavy data, where a plain 8-byte
-// prefix ties on every probe and every tie costs a text compare, almost every probe is decided by one load.
-constexpr int DICT_RUN_CAP = 254;
-// run: the length of the run of s[0] at s if the caller knows it (the text's `rlen`, capped at 255; it may exceed A), else < 0.
-// w0: the first 8 bytes of s (little-endian load); a run of up to 3 leaves the whole tail inside it, so the common
-// case costs no load of its own
-__device__ inline uint64_t run_key_w(const uint8_t *s, int A, int &rlc, int run, uint64_t w0) {
-    const uint32_t c = (uint32_t)(w0 & 0xFFull);
-    const int lim = (A - 1) < DICT_RUN_CAP ? (A - 1) : DICT_RUN_CAP;
-    const int rl = run < 0 ? 1 + lcp_bytes(s, s + 1, 0, lim) : (run < lim + 1 ? run : lim + 1);
-    if (rl >= DICT_RUN_CAP) {
-        rlc = DICT_RUN_CAP;
-        return ((uint64_t)c << 49) | (255ull << 40);
-    }
-    rlc = rl;
-    uint64_t tail = 0;
-    bool falling = true;
-    if (rl < A) {
-        const int avail = A - rl;
-        const uint64_t w = rl <= 3 ? (w0 >> (8 * rl)) : ld8(s + rl);
-        tail = (__builtin_bswap64(w) >> 24) & ((1ull << 40) - 1ull);
-        if (avail < 5) tail &= ~((1ull << (8 * (5 - avail))) - 1ull);
-        falling = (uint32_t)(w & 0xFFull) < c;
-    }
-    const uint64_t code = falling ? (uint64_t)rl : (uint64_t)(511 - rl);
-    return ((uint64_t)c << 49) | (code << 40) | tail;
-}
-__device__ inline uint64_t run_key(const uint8_t *s, int A, int &rlc) { return run_key_w(s, A, rlc, -1, ld8(s)); }
-// common prefix length of two strings from their (different) keys; the caller caps it by the strings' lengths
-__device__ inline int key_lcp(uint64_t a, uint64_t b) {
-    if ((a ^ b) >> 49) return 0;
-    const int ca = (int)(a >> 40) & 511, cb = (int)(b >> 40) & 511;
-    const int ra = ca == 255 ? DICT_RUN_CAP : (ca < 255 ? ca : 511 - ca);
-    const int rb = cb == 255 ? DICT_RUN_CAP : (cb < 255 ? cb : 511 - cb);
-    if (ca != cb) return ra < rb ? ra : rb;
-    const uint64_t x = (a ^ b) & ((1ull << 40) - 1ull);
-    return ra + (((int)__builtin_clzll(x) - 24) >> 3);
 }
 
 // Auxiliary arrays of the dictionary index: a run-aware 8-byte key per rank (one load decides almost every probe
@@ -417,7 +453,7 @@ __device__ inline void dict_search_in(const DictView &D, const uint8_t *pat, int
 // reads only) and phase B searches inside it, where every probe is a text compare - one or two steps instead of six.
 template <class KeyAt, class SaAt>
 __device__ inline void dict_search_staged(const DictView &D, const uint8_t *pat, int maxLen, uint64_t pk, int prl, int &lo, int &hi,
-                                          int &elo, int &ehi, KeyAt key_at, SaAt sa_at) {
+                                          int &elo, int &ehi, KeyAt key_at, SaAt sa_at MP_ARG) {
     elo = -1;
     ehi = -1;
     {   // phase A: the first rank whose key is >= pk, then the first whose key is > pk (hi itself is never read)
@@ -436,6 +472,7 @@ __device__ inline void dict_search_staged(const DictView &D, const uint8_t *pat,
         }
         hi = h;
     }
+    MP(12)
     while (hi - lo > 1) {  // phase B: every rank between has the key pk
         const int mid = (lo + hi) >> 1;
         const int q = sa_at(mid);
@@ -553,17 +590,16 @@ __global__ __launch_bounds__(64) void dict_bounds_kernel(const Seg *segs, uint32
 
 // hF / hL: lower bounds of the block's first rank and of the next block's first rank (D.n + 1 past the last block)
 __device__ inline void dict_lookup_wave(const DictView &D, const uint64_t *s_key, const int32_t *s_dsa, bool staged, int LB, int hL,
-                                        bool need, const uint8_t *pat, int maxLen, int &Ld, int &kd, int run, uint64_t w0 MP_ARG) {
+                                        bool need, const uint8_t *pat, int maxLen, int &Ld, int &kd, uint64_t pk MP_ARG) {
     Ld = 0;
     kd = 0;
     if (!need) return;
-    int prl = 0;
-    const uint64_t pk = run_key_w(pat, maxLen, prl, run, w0);
+    const int prl = key_run(pk);  // pk: run_key of pat[0:maxLen) (pattern_word)
     int lo = LB, hi = hL, elo, ehi;
     int q2[2];
     uint64_t k2[2];
     if (staged) {
-        dict_search_staged(D, pat, maxLen, pk, prl, lo, hi, elo, ehi, [&](int k) { return s_key[k - LB]; }, [&](int k) { return s_dsa[k - LB]; });
+        dict_search_staged(D, pat, maxLen, pk, prl, lo, hi, elo, ehi, [&](int k) { return s_key[k - LB]; }, [&](int k) { return s_dsa[k - LB]; } MP_PASS);
         q2[0] = s_dsa[lo - LB]; q2[1] = s_dsa[lo - LB + 1];
         k2[0] = s_key[lo - LB]; k2[1] = s_key[lo - LB + 1];
     } else {
@@ -662,14 +698,9 @@ __global__ __launch_bounds__(MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(M
     bool work = r >= 1 && r < N;
     int i = work ? SA[r] : 0;
     work = work && !(i < (int)sg.start || i < HEAD);
-    // the lane's own scattered reads, issued together: the first 8 text bytes (reserved-symbol test, dictionary key)
-    // and the run lengths at i - 2 .. i + 1 (RLE skip test, dictionary key)
-    uint64_t w0 = 0;
-    uint32_t rl4 = 0;
-    if (work) {  // i >= HEAD > 2
-        w0 = ld8(T + i);
-        __builtin_memcpy(&rl4, ix.rlen + sg.off + i - 2, 4);
-    }
+    // what the LCP kernel left for this rank (pattern_word): the pattern's dictionary key and the RLE skip flag - one
+    // coalesced load instead of gathers of the text and the run lengths at the lane's position
+    const uint64_t pkw = (r >= 1 && r < N) ? ix.pkey[sg.off + r] : 0ull;
     for (int j = lane; j < WIN_TOTAL; j += 64) {
         int g = wbase + j;
         g = g < 0 ? 0 : (g > N + 3 ? N + 3 : g);  // LCP is zero at rank 0 and from N to N + 3: walks die there
@@ -694,12 +725,12 @@ __global__ __launch_bounds__(MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(M
     __syncthreads();
     // the walk can never call bestBackref(i) when i, i-1 and i-2 lie in one run of equal bytes and at least 160 of them
     // follow i: the RLE branch (compress.go:184) is taken at i, i-1 and i-2 (run lengths capped at 255)
-    if (work && skip_unqueried && (rl4 & 0xFFu) >= LZSS_MIN_REPEAT + 2) {
+    if (work && skip_unqueried && (pkw & PKEY_SKIP)) {
         res[sg.off + i] = res_pack(RES_NONE, 0, 0);
         work = false;
     }
     const int maxLen = (n - i) < LZSS_MAX_LEN ? (n - i) : LZSS_MAX_LEN;
-    const bool reserved = work && (w0 & 0xFFull) >= LZSS_SYMBOL_SHORT;
+    const bool reserved = work && (uint32_t)((pkw >> 49) & 0xFFull) >= LZSS_SYMBOL_SHORT;
     const int minS = reserved ? 1 : LZSS_SHORT_MIN_LEN;
     const int minD = reserved ? 1 : LZSS_DYN_MIN_LEN;
     const bool shortOK = maxLen >= minS, dynOK = maxLen >= minD;
@@ -916,7 +947,7 @@ __global__ __launch_bounds__(MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // bounds of its first and last lane and finishes inside LDS (dict_lookup_wave)
     int Ld = 0, kd = 0;
     dict_lookup_wave(D, s_dkey, s_dsa, dstaged, dLB, dhL, work && dynOK && LL < maxLen && !(ablate & 1), T + i, maxLen, Ld, kd,
-                     (int)((rl4 >> 16) & 0xFFu), w0 MP_PASS);
+                     pkw & PKEY_KEY_MASK MP_PASS);
     MP(7)
     // selection (compress.go:160-169) BEFORE the offsets: only the window whose reference is emitted needs its
     // smallest-rank occurrence, so every lane runs at most one interval search
