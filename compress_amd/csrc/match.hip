@@ -645,7 +645,14 @@ __device__ inline uint32_t select_backref(const DictView &D, int i, int minD, bo
 #define MATCH_SCAN_CAP 7   // (measured per 10 000 blobs: 4 55.2, 5 53.7, 6 53.2, 7 52.9, 8 53.9, 12 56.6 ms)
 #endif
 constexpr int SCAN_CAP = MATCH_SCAN_CAP;  // x4 ranks a lane walks alone before its wave takes the walk over
-constexpr int WIN_HALO = 4 * SCAN_CAP + 4;                // ranks staged in LDS on each side of the wave's 64
+// ranks staged in LDS on each side of the wave's 64: what the lane-private walks reach (4 * SCAN_CAP + 4).  A wider
+// window also serves the first 64-rank step of the walks the wave takes over (they check for it), but staging 96 ranks
+// per side so that every such first step is an LDS read gained nothing: 48.8 vs 48.6 ms (64 with SCAN_CAP 5: 48.9)
+#ifndef MATCH_STAGE_HALO
+#define MATCH_STAGE_HALO (4 * MATCH_SCAN_CAP + 4)
+#endif
+constexpr int WIN_HALO = MATCH_STAGE_HALO;
+static_assert(WIN_HALO >= 4 * SCAN_CAP + 4 && WIN_HALO % 4 == 0, "the lane-private walks read the staged window only");
 constexpr int WIN_TOTAL = 64 + 2 * WIN_HALO;
 
 __device__ inline uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
@@ -689,7 +696,7 @@ __global__ __launch_bounds__(MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // lane-private part of the walks then reads LDS instead of issuing 64 overlapping 16-byte loads per step
     static_assert(MATCH_THREADS == 64, "one wave per block: the window belongs to the wave");
     __shared__ int32_t s_sa[WIN_TOTAL + 4];
-    __shared__ uint32_t s_lc[WIN_TOTAL + 4];
+    __shared__ uint16_t s_lc[WIN_TOTAL + 4];  // (lcp <= 256)
     __shared__ uint64_t s_dkey[DICT_WIN + 2];  // the wave's bracket of the dictionary (dict_lookup_wave)
     __shared__ int32_t s_dsa[DICT_WIN + 2];
     const int wbase = (int)(bx * MATCH_THREADS) - WIN_HALO;
@@ -792,8 +799,13 @@ __global__ __launch_bounds__(MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(M
                 DS(12, 1)
                 const int kk = base + lane;
                 const bool valid = kk < N;
-                const int l = valid ? (int)LCP[kk] : 0;
-                const int p = valid ? SA[kk] : 0x7FFFFFFF;
+                int l = 0, p = 0x7FFFFFFF;
+                if (base - wbase + 64 <= WIN_TOTAL) {  // (base >= wbase: the walk starts above the wave's first rank)
+                    if (valid) { l = (int)s_lc[kk - wbase]; p = s_sa[kk - wbase]; }
+                } else if (valid) {
+                    l = (int)LCP[kk];
+                    p = SA[kk];
+                }
                 int pm = wave_incl_min(l, lane);
                 pm = pm < cm ? pm : cm;
                 if (!cfL) {
@@ -892,8 +904,13 @@ __global__ __launch_bounds__(MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(M
                 DS(14, 1)
                 const int kk = base - lane;
                 const bool valid = kk >= 1;
-                const int l = valid ? (int)LCP[kk + 1] : 0;
-                const int p = valid ? SA[kk] : 0x7FFFFFFF;
+                int l = 0, p = 0x7FFFFFFF;
+                if (base - 63 >= wbase) {  // (base + 1 < wbase + WIN_TOTAL: the walk starts below the wave's last rank)
+                    if (valid) { l = (int)s_lc[kk + 1 - wbase]; p = s_sa[kk - wbase]; }
+                } else if (valid) {
+                    l = (int)LCP[kk + 1];
+                    p = SA[kk];
+                }
                 int pm = wave_incl_min(l, lane);
                 pm = pm < cm ? pm : cm;
                 if (!cfL) {
