@@ -98,6 +98,66 @@ def test_run_compressed_sort_matches_oracle(amd):
         assert outs[k] == oc.compress(d), f"case {k}"
 
 
+def sparse_window_cases():
+    """short-window references whose smallest-rank occurrence lies behind many ranks outside the window: an 8-byte word
+    followed by 0x00 at `far` places outside the window (the smallest ranks of the word's interval), by 0x01 inside the
+    window, by 0x02 where it is compressed - the searches through the window index (window_search.h: leftmost), with
+    intervals on both sides of its linear-scan threshold, and with windows that start at the text's start"""
+    rng = np.random.default_rng(1614)
+
+    def filler(n):
+        return bytes(rng.integers(3, 250, n, dtype=np.uint8))
+
+    def word():
+        return bytes(rng.integers(3, 250, 8, dtype=np.uint8))
+
+    cases = []
+    # the window starts behind the far copies; 20 .. 100 of them: found by the scan, 130 .. 400: the index is needed
+    t = bytearray(filler(100000))
+    words = [(word(), far) for far in (20, 27, 28, 29, 56, 57, 100, 111, 112, 113, 130, 400)]
+    pos = 100
+    for w, far in words:
+        for _ in range(far):
+            t[pos:pos + 9] = w + b"\x00"
+            pos += 80
+    assert pos < 99000
+    t += filler(30000)
+    for k, (w, far) in enumerate(words):
+        t[125000 + 40 * k:125000 + 40 * k + 9] = w + b"\x01"
+    for k, (w, far) in enumerate(words):
+        t += filler(30) + w + b"\x02"
+    cases.append(bytes(t) + filler(50))
+    # the window starts at the text's start: the copies outside it lie BEHIND the compressed position
+    t = bytearray(filler(1000))
+    words = [(word(), far) for far in (10, 40, 200)]
+    for w, far in words:
+        t += filler(20) + w + b"\x01"
+    t += filler(1500)
+    for w, far in words:
+        t += filler(20) + w + b"\x02"
+    t += filler(500)
+    for w, far in words:
+        for _ in range(far):
+            t += filler(50) + w + b"\x00"
+    cases.append(bytes(t))
+    return cases
+
+
+def test_short_window_searches_with_sparse_hits(amd):
+    cases = sparse_window_cases()
+    ctx = amd.batch.new_ctx(b"")
+    b = amd.batch.Batch(ctx, len(cases), sum(map(len, cases)))
+    oc = O.Compressor(b"")
+    want = [oc.compress(d) for d in cases]
+    for order in (cases, cases[::-1]):
+        b.upload(order)
+        b.compress()
+        outs = b.download()
+        exp = want if order is cases else want[::-1]
+        for k in range(len(cases)):
+            assert outs[k] == exp[k], f"case {k}"
+
+
 def small_group_cases():
     """inputs that stress the suffix sort's small-group finisher (sa_finish) and the LDS / global LCP kernels"""
     rng = np.random.default_rng(11)
