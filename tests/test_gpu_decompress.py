@@ -72,6 +72,45 @@ def test_batch_roundtrip_matches_oracle(amd, dict_naive, average_block):
     assert got[9] == inputs[9]
 
 
+def test_fast_loop_boundaries(amd, dict_naive, average_block):
+    """decompress_kernel's fast loop runs while 512 bits of stream and 320 bytes of capacity are left, the checked loop
+    finishes: capacities from exact to generous, streams cut at every length around the switch, long literal runs (steps of
+    63 literals), references shorter than a word (single reserved bytes), overlapping copies, dictionary sources"""
+    rng = np.random.default_rng(77)
+    inputs = [
+        bytes(rng.integers(0, 254, 4000, dtype=np.uint8)),                                   # literals only
+        bytes(rng.integers(0, 256, 3000, dtype=np.uint8)),                                   # literals and one-byte references
+        b"".join(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 9)) for _ in range(900)),   # short overlapping copies
+        dict_naive[100:700] + bytes(rng.integers(0, 254, 200, dtype=np.uint8)) + dict_naive[50:400],   # dictionary sources
+        average_block[:6000],
+        bytes(rng.integers(0, 254, 70, dtype=np.uint8)),                                     # a stream of about 64 bytes
+        b"ab" * 40 + bytes(rng.integers(0, 254, 30, dtype=np.uint8)),
+    ]
+    oc = O.Compressor(dict_naive)
+    ctx = amd.batch.new_ctx(dict_naive)
+    streams, caps, want = [], [], []
+    for d in inputs:
+        st = bytes(oc.compress(d))
+        for extra in (0, 1, 63, 64, 319, 320, 321, 1000):
+            streams.append(st); caps.append(len(d) + extra); want.append(d)
+        streams.append(st); caps.append(len(d) - 1); want.append(None)                       # one byte short: E_CAPACITY
+        for ln in sorted({len(st) - c for c in list(range(1, 12)) + [60, 64, 65, 70]} | {66, 67, 68, 69}):
+            if not 3 <= ln < len(st):
+                continue
+            t = st[:ln]                                                                      # a stream cut short
+            try:
+                w = O.decompress(t, dict_naive)
+            except O.OracleError:
+                w = None
+            streams.append(t); caps.append(len(d) + 400); want.append(w)
+    got = amd.decompress_batch(ctx, streams, caps)
+    for k in range(len(streams)):
+        if want[k] is None:
+            assert isinstance(got[k], amd.LzssError), k
+        else:
+            assert got[k] == want[k], k
+
+
 def test_gpu_compress_then_gpu_decompress_config5(amd):
     """config 5 shape: compressed synthetic 128 KiB blobs (overlapping run-length references included)"""
     dict_ = amd.synth.dictionary()
