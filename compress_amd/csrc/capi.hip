@@ -116,7 +116,7 @@ struct mi355_lzss_ctx {
     // per part: the head positions' brute-force search and the dictionary brackets (no LDS, few registers) run on a stream
     // of their own beside the LCP kernel, which fills a CU's LDS with half of its wave slots
     hipStream_t aux[kMaxSplit] = {};
-    hipEvent_t sa_ev[kMaxSplit] = {}, head_ev[kMaxSplit] = {};
+    hipEvent_t sa_ev[kMaxSplit] = {}, head_ev[kMaxSplit] = {}, win_ev[kMaxSplit] = {};
     int split = 2;
     // workspaces of the entry points that may be called concurrently (compressed_size: compress.go:381-383)
     std::mutex pool_mu;
@@ -438,7 +438,14 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
         if (!ctx->aux[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[k], hipStreamNonBlocking));
         if (!ctx->sa_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->sa_ev[k], hipEventDisableTiming));
         if (!ctx->head_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->head_ev[k], hipEventDisableTiming));
+        if (!ctx->win_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->win_ev[k], hipEventDisableTiming));
     }
+    // match_kernel leaves the smallest-rank searches to the emitter (launch_match: defer), so nothing reads the window
+    // index before the emitter does
+    bool deferred = skip_unqueried && b->max_n + 1 < RES_DEFER_MAX_N;
+#ifdef LZSS_DEBUG_KNOBS
+    if (getenv("MI355_LZSS_NO_DEFER")) deferred = false;
+#endif
     if ((rc = mark(b, ST_SA)) != 0) return rc;
     HIP_TRY(hipEventRecord(ctx->fork_ev, sm));
     for (int k = 0; k < split; ++k) {
@@ -452,13 +459,18 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
         HIP_TRY(hipStreamWaitEvent(ctx->aux[k], ctx->sa_ev[k], 0));
         launch_match_head(sg, cnt, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), ctx->aux[k]);
         HIP_TRY(hipEventRecord(ctx->head_ev[k], ctx->aux[k]));
+        // the window index (only the emitter's searches read it) on the side stream, beside the LCP and match kernels
+        launch_window_index(sg, cnt, b->max_n, batch_index(b), ctx->aux[k], true, false);
+        HIP_TRY(hipEventRecord(ctx->win_ev[k], ctx->aux[k]));
         launch_lcp(sg, cnt, b->max_n, batch_index(b), st);
-        launch_window_index(sg, cnt, b->max_n, batch_index(b), st);
+        launch_window_index(sg, cnt, b->max_n, batch_index(b), st, false, true);  // block minima of the suffix array, second level
         HIP_TRY(hipStreamWaitEvent(st, ctx->head_ev[k], 0));
+        if (!deferred) HIP_TRY(hipStreamWaitEvent(st, ctx->win_ev[k], 0));  // match_kernel itself searches the window index
         launch_match(sg, cnt, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), skip_unqueried, st);
         if (k) HIP_TRY(hipEventRecord(ctx->join_ev[k], st));
     }
     for (int k = 1; k < split; ++k) HIP_TRY(hipStreamWaitEvent(sm, ctx->join_ev[k], 0));
+    for (int k = 0; k < split; ++k) HIP_TRY(hipStreamWaitEvent(sm, ctx->win_ev[k], 0));
     for (int k = ST_LCP; k <= ST_DECIDE; ++k)
         if ((rc = mark(b, k)) != 0) return rc;
     HIP_TRY(hipGetLastError());
@@ -901,6 +913,7 @@ extern "C" void mi355_lzss_ctx_destroy(mi355_lzss_ctx *ctx) {
         if (ctx->aux[k]) (void)hipStreamDestroy(ctx->aux[k]);
         if (ctx->sa_ev[k]) (void)hipEventDestroy(ctx->sa_ev[k]);
         if (ctx->head_ev[k]) (void)hipEventDestroy(ctx->head_ev[k]);
+        if (ctx->win_ev[k]) (void)hipEventDestroy(ctx->win_ev[k]);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

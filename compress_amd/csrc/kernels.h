@@ -74,7 +74,10 @@ struct BatchIndex {   // batch-wide index arrays
     // (in ks; ps is not written), which halves what window_index_kernel writes and what the summaries read
     uint32_t win_packed;
 };
-void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream);
+// index: the window index proper; summaries: the second level of the suffix array's block minima (the first is the LCP
+// kernel's), which the long-window search reads
+void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream,
+                         bool index = true, bool summaries = true);
 void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream);
 // skip_unqueried: leave out positions the walk provably never asks about (deep inside a run of >= 160
 // equal bytes, compress.go:180-218); their result is then RES_NONE

@@ -2162,9 +2162,11 @@ void launch_isa_from_sa(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, cons
     hipLaunchKernelGGL(isa_from_sa_kernel, dim3((max_n + 256) / 256, n_segs), dim3(256), 0, stream, d_segs, d_sa, d_isa);
 }
 
-void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream) {
+void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream,
+                         bool index, bool summaries) {
     if (n_segs == 0 || max_n == 0) return;
-    hipLaunchKernelGGL(window_index_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, ix);
+    if (index) hipLaunchKernelGGL(window_index_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, ix);
+    if (!summaries) return;
     const uint32_t c0 = max_n + 1, c1 = (c0 + 63) / 64;
     dim3 g1((c1 + 255) / 256, n_segs);
     hipLaunchKernelGGL(block64_kernel<false>, g1, dim3(256), 0, stream, d_segs, ix.samin1, ix.samin2, 1, 1);  // samin1: lcp_kernel
