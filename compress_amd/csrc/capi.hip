@@ -418,7 +418,10 @@ static int run_index_and_match(mi355_lzss_batch *b, bool skip_unqueried) {
         if ((rc = mark(b, ST_LCP)) != 0) return rc;
         launch_lcp(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
         if ((rc = mark(b, ST_WINDEX)) != 0) return rc;
-        launch_window_index(d_segs, b->n_blobs, b->max_n, batch_index(b), sm);
+        {
+            const SaWork wk = sa_work(b);  // (scratch for the device-wide index of texts above 2^19 suffixes)
+            launch_window_index(d_segs, b->n_blobs, b->max_n, batch_index(b), sm, true, true, b->h_segs.data(), &wk);
+        }
         if ((rc = mark(b, ST_MHEAD)) != 0) return rc;
         launch_match_head(d_segs, b->n_blobs, b->max_n, batch_index(b), ctx->view, b->res.as<uint32_t>(), sm);
         if ((rc = mark(b, ST_MATCH)) != 0) return rc;

@@ -76,8 +76,12 @@ struct BatchIndex {   // batch-wide index arrays
 };
 // index: the window index proper; summaries: the second level of the suffix array's block minima (the first is the LCP
 // kernel's), which the long-window search reads
+// h_segs / wk: with them, the texts of more than SA_BITMAP_MAX_N suffixes get their index from the device-wide routine of
+// sa_large.hip (launch_window_large; scratch: wk->rkA, rkB, pairs, tmp) instead of the one-workgroup kernel
 void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream,
-                         bool index = true, bool summaries = true);
+                         bool index = true, bool summaries = true, const Seg *h_segs = nullptr, const SaWork *wk = nullptr);
+size_t window_large_temp_bytes(uint32_t n);
+int launch_window_large(const Seg &sg, const BatchIndex &ix, const SaWork &wk, hipStream_t stream);
 void launch_lcp(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream);
 // skip_unqueried: leave out positions the walk provably never asks about (deep inside a run of >= 160
 // equal bytes, compress.go:180-218); their result is then RES_NONE

@@ -2026,11 +2026,11 @@ __device__ inline uint64_t chunk_peers(int c, uint64_t amask, int cbits) {
     return match_digit_n(c, amask, cbits);
 }
 
-__global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *segs, BatchIndex ix) {
+__global__ __launch_bounds__(SA_THREADS) void window_index_kernel(const Seg *segs, BatchIndex ix, uint32_t skip_above) {
     __shared__ SaShared sh;
     const Seg sg = segs[blockIdx.x];
     const uint32_t n = sg.n;
-    if (n == 0) return;
+    if (n == 0 || n + 1 > skip_above) return;  // (texts of more suffixes than skip_above: launch_window_large)
     const uint32_t N = n + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int32_t *SA = ix.sa + sg.off;
@@ -2163,9 +2163,17 @@ void launch_isa_from_sa(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, cons
 }
 
 void launch_window_index(const Seg *d_segs, uint32_t n_segs, uint32_t max_n, const BatchIndex &ix, hipStream_t stream,
-                         bool index, bool summaries) {
+                         bool index, bool summaries, const Seg *h_segs, const SaWork *wk) {
     if (n_segs == 0 || max_n == 0) return;
-    if (index) hipLaunchKernelGGL(window_index_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, ix);
+    if (index) {
+        const bool large = h_segs && wk && wk->tmp && max_n + 1 > SA_BITMAP_MAX_N;
+        hipLaunchKernelGGL(window_index_kernel, dim3(n_segs), dim3(SA_THREADS), 0, stream, d_segs, ix,
+                           large ? SA_BITMAP_MAX_N : 0xFFFFFFFFu);
+        if (large)
+            for (uint32_t k = 0; k < n_segs; ++k)
+                if (h_segs[k].n + 1 > SA_BITMAP_MAX_N && launch_window_large(h_segs[k], ix, *wk, stream) != 0)
+                    hipLaunchKernelGGL(window_index_kernel, dim3(1), dim3(SA_THREADS), 0, stream, d_segs + k, ix, 0xFFFFFFFFu);
+    }
     if (!summaries) return;
     const uint32_t c0 = max_n + 1, c1 = (c0 + 63) / 64;
     dim3 g1((c1 + 255) / 256, n_segs);

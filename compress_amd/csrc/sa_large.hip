@@ -116,4 +116,108 @@ int launch_sa_large(const Seg &sg, const uint8_t *d_text, const SaWork &wk, hipS
     return 0;
 }
 
+// ---- the window index of ONE large text on the whole device --------------------------------------------------
+// (sa_build.hip: window_index_kernel is one workgroup per text - 9 to 12 of the ~30 ms of a 4 MiB text.)  The index is
+// the ranks 1..n grouped by the 16 KiB chunk of their position, rank order kept inside a chunk: a stable sort by the chunk
+// number, i.e. ONE 8-bit radix pass over (chunk, rank) pairs.  Every chunk but the last holds exactly 16 384 positions and
+// every position has one rank, so chunk c's list starts at entry c * 16 384 by itself - the layout the searches expect
+// (window_search.h).  The chunk directory (entries of chunk c with a rank below 1 + 64 b, for every block b of 64 ranks)
+// follows from the places where the block of the rank changes along a chunk's list: entry j of the list writes its
+// own number into the rows of the blocks between its predecessor's and its own.
+constexpr int WIL_THREADS = 256;
+
+__global__ __launch_bounds__(WIL_THREADS) void wil_keys_kernel(const int32_t *SA, uint32_t n, uint32_t *keys, uint32_t *vals) {
+    const uint32_t j = blockIdx.x * WIL_THREADS + threadIdx.x;  // entry j of the unsorted list: rank j + 1
+    if (j >= n) return;
+    keys[j] = (uint32_t)SA[j + 1] >> LZSS_SHORT_ADDR_BITS;
+    vals[j] = j + 1;
+}
+
+// PS[j] = position of the suffix of rank KS[j]; min / max of the positions over blocks of 64 entries
+__global__ __launch_bounds__(WIL_THREADS) void wil_positions_kernel(const int32_t *SA, const int32_t *KS, uint32_t n, int32_t *PS,
+                                                                    int32_t *pmin1, int32_t *pmax1) {
+    const uint32_t j = blockIdx.x * WIL_THREADS + threadIdx.x;
+    int lo = INT_MAX, hi = INT_MIN;
+    if (j < n) {
+        const int p = SA[KS[j]];
+        PS[j] = p;
+        lo = hi = p;
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0 && j < n) {
+        pmin1[j >> 6] = lo;
+        pmax1[j >> 6] = hi;
+    }
+}
+
+// cdir[b * row + c] for every block b of 64 ranks, b < nb1, and every chunk c of the text
+__global__ __launch_bounds__(WIL_THREADS) void wil_directory_kernel(const int32_t *KS, uint32_t n, uint32_t nb1, uint32_t row,
+                                                                    uint16_t *cdir) {
+    const uint32_t j = blockIdx.x * WIL_THREADS + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t c = j >> LZSS_SHORT_ADDR_BITS, jj = j & (LZSS_SHORT_WINDOW - 1);
+    const uint32_t first = c << LZSS_SHORT_ADDR_BITS;
+    const uint32_t cnt = n - first < (uint32_t)LZSS_SHORT_WINDOW ? n - first : (uint32_t)LZSS_SHORT_WINDOW;  // entries of chunk c
+    const uint32_t bj = ((uint32_t)KS[j] - 1u) >> 6;                       // block of this entry's rank (ranks start at 1)
+    uint32_t b = jj == 0 ? 0u : (((uint32_t)KS[j - 1] - 1u) >> 6) + 1u;    // first block behind the predecessor's
+    for (; b <= bj && b < nb1; ++b) cdir[(size_t)b * row + c] = (uint16_t)jj;   // the entries before this one have smaller ranks
+    if (jj == cnt - 1)
+        for (b = bj + 1; b < nb1; ++b) cdir[(size_t)b * row + c] = (uint16_t)cnt;
+}
+
+__global__ __launch_bounds__(WIL_THREADS) void wil_level2_kernel(const int32_t *pmin1, const int32_t *pmax1, uint32_t nb1, int32_t *pmin2,
+                                                                 int32_t *pmax2) {
+    const uint32_t j = blockIdx.x * WIL_THREADS + threadIdx.x;
+    int lo = INT_MAX, hi = INT_MIN;
+    if (j < nb1) {
+        lo = pmin1[j];
+        hi = pmax1[j];
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0 && j < nb1) {
+        pmin2[j >> 6] = lo;
+        pmax2[j >> 6] = hi;
+    }
+}
+
+size_t window_large_temp_bytes(uint32_t n) {
+    size_t a = 0;
+    rocprim::double_buffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, a, dk, dv, (size_t)n, 0u, 8u, (hipStream_t)0);
+    return a + 256;
+}
+
+// scratch: wk.rkA / wk.rkB (the chunk numbers, in and out), wk.pairs (the ranks before the sort), wk.tmp (rocPRIM's);
+// the suffix array and its first-level block minima must be complete.  Returns hipSuccess or the first error.
+int launch_window_large(const Seg &sg, const BatchIndex &ix, const SaWork &wk, hipStream_t stream) {
+    const uint32_t n = sg.n;
+    if (n == 0) return 0;
+    if (!wk.tmp || !wk.rkA || !wk.rkB || !wk.pairs || wk.tmp_bytes < window_large_temp_bytes(n)) return (int)hipErrorInvalidValue;
+    const int32_t *SA = ix.sa + sg.off;
+    int32_t *KS = ix.ks(sg), *PS = ix.ps(sg);
+    uint32_t *kA = reinterpret_cast<uint32_t *>(wk.rkA + sg.off), *kB = reinterpret_cast<uint32_t *>(wk.rkB + sg.off);
+    uint32_t *vA = wk.pairs + sg.off, *vB = reinterpret_cast<uint32_t *>(KS);
+    const uint32_t blocks = (n + WIL_THREADS - 1) / WIL_THREADS;
+    hipError_t e;
+    hipLaunchKernelGGL(wil_keys_kernel, dim3(blocks), dim3(WIL_THREADS), 0, stream, SA, n, kA, vA);
+    rocprim::double_buffer<uint32_t> dk(kA, kB), dv(vA, vB);
+    void *tmp = wk.tmp + 256;
+    size_t tmp_bytes = wk.tmp_bytes - 256;
+    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, (size_t)n, 0u, 8u, stream);  // stable: rank order inside a chunk
+    if (e != hipSuccess) return (int)e;
+    if (dv.current() != vB) hipLaunchKernelGGL(sal_copy_kernel, dim3(blocks), dim3(WIL_THREADS), 0, stream, dv.current(), n, KS);
+    const uint32_t nb1 = (n + 63) / 64;
+    hipLaunchKernelGGL(wil_positions_kernel, dim3(blocks), dim3(WIL_THREADS), 0, stream, SA, KS, n, PS, ix.pmin1 + sg.off / 64,
+                       ix.pmax1 + sg.off / 64);
+    hipLaunchKernelGGL(wil_directory_kernel, dim3(blocks), dim3(WIL_THREADS), 0, stream, KS, n, nb1, ix.nch,
+                       ix.cdir + (size_t)(sg.off / 64) * ix.nch);
+    // second level of the min / max summaries: blocks of 64 first-level entries
+    hipLaunchKernelGGL(wil_level2_kernel, dim3((nb1 + WIL_THREADS - 1) / WIL_THREADS), dim3(WIL_THREADS), 0, stream,
+                       ix.pmin1 + sg.off / 64, ix.pmax1 + sg.off / 64, nb1, ix.pmin2 + sg.off / 64, ix.pmax2 + sg.off / 64);
+    e = hipGetLastError();
+    return (int)e;
+}
+
 }  // namespace lzss
